@@ -1,0 +1,64 @@
+"""Builds the committed fixtures under tests/golden/ from DATA files of the reference.
+
+Run once in the build container (``python tests/golden/make_golden.py``); the
+reference tree does not travel to the GPU box, the fixtures do.
+
+Origins (every expected value is labelled):
+* ``gray_kat.npz``     -- origin ``cv2-artefact``.  NewVersion2/inverted.png and
+  NewVersion2/gray_img.png were written by real cv2 from one (un-shipped) input
+  (NewVersion2/text_detectionv2.py:22-30): ``inverted = bitwise_not(bgr)``,
+  ``gray = cvtColor(bgr, BGR2GRAY)``.  ``255 - inverted`` recovers the BGR input
+  (PNG is lossless; PIL reads RGB so the channel order is reversed back).  The
+  fixture keeps the 256 rows x 320 cols window holding the most coloured pixels
+  plus every distinct colour of the full image with its gray value.
+* ``cd.npz`` / ``login.npz`` -- decoded BGR pixels of images/cd.png (the
+  config-0 input) and images/login.png (what lineDetection.py:5 loads); inputs
+  only, ``restatement`` outputs are derived in the tests.
+"""
+import os
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_bgr(path):
+    return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
+
+
+def main():
+    inv_rgb = np.asarray(Image.open(f"{REF}/NewVersion2/inverted.png").convert("RGB"))
+    gray = np.asarray(Image.open(f"{REF}/NewVersion2/gray_img.png").convert("L"))
+    inv_bgr = inv_rgb[..., ::-1]
+    bgr = 255 - inv_bgr
+    coloured = (bgr.max(axis=2) != bgr.min(axis=2)).astype(np.int64)
+    H, W = gray.shape
+    ch, cw = 256, 320
+    ii = np.pad(coloured.cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+    best, by, bx = -1, 0, 0
+    for y in range(0, H - ch + 1, 8):
+        for x in range(0, W - cw + 1, 8):
+            s = ii[y + ch, x + cw] - ii[y, x + cw] - ii[y + ch, x] + ii[y, x]
+            if s > best:
+                best, by, bx = s, y, x
+    flat = np.concatenate([bgr.reshape(-1, 3), gray.reshape(-1, 1)], axis=1)
+    uniq = np.unique(flat, axis=0)
+    np.savez_compressed(
+        f"{OUT}/gray_kat.npz",
+        bgr=bgr[by : by + ch, bx : bx + cw].copy(),
+        inverted_bgr=inv_bgr[by : by + ch, bx : bx + cw].copy(),
+        gray=gray[by : by + ch, bx : bx + cw].copy(),
+        colours_bgr=uniq[:, :3].astype(np.uint8),
+        colours_gray=uniq[:, 3].astype(np.uint8),
+    )
+    print("gray KAT window", (by, bx), "coloured px", best, "distinct colour->gray rows", len(uniq))
+    for name in ("cd", "login"):
+        a = load_bgr(f"{REF}/images/{name}.png")
+        np.savez_compressed(f"{OUT}/{name}.npz", bgr=a)
+        print(name, a.shape)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+"""CPU-only checks of the oracle itself: cv2-written artefact, hand-derived known
+answers, and C restatement vs the independent numpy/scipy restatement.
+
+Origin labels: ``cv2-artefact`` = produced by real cv2 and shipped in the
+reference tree; ``analytic`` = derived by hand from the OpenCV definitions;
+``restatement`` = agreement of two independently written restatements.
+"""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from oracle import frontref as fr
+from oracle import np_ref as nr
+
+
+# ---------------------------------------------------------------- cv2-artefact
+def test_gray_kat_window(gray_kat):
+    assert np.array_equal(fr.bgr2gray(gray_kat["bgr"]), gray_kat["gray"])
+    assert np.array_equal(nr.bgr2gray(gray_kat["bgr"]), gray_kat["gray"])
+
+
+def test_gray_kat_all_colours(gray_kat):
+    cols = gray_kat["colours_bgr"][None, :, :]
+    assert np.array_equal(fr.bgr2gray(cols)[0], gray_kat["colours_gray"])
+
+
+def test_bitwise_not_kat(gray_kat):
+    assert np.array_equal(fr.bitwise_not(gray_kat["bgr"]), gray_kat["inverted_bgr"])
+
+
+# ---------------------------------------------------------------- analytic
+def test_gray_primaries():
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0]]], np.uint8)
+    assert fr.bgr2gray(px).tolist() == [[29, 150, 76, 255, 0]]
+
+
+@pytest.mark.parametrize("t", [100, 127, 128, 150, 200, 240])
+def test_threshold_truth_table(t):
+    g = np.array([[0, t - 1, t, t + 1, 255]], np.uint8)
+    r, d = fr.threshold(g, t, 255, 1)
+    assert r == float(t) and d.tolist() == [[255, 255, 255, 0, 0]]
+    r, d = fr.threshold(g, t, 255, 0)
+    assert d.tolist() == [[0, 0, 0, 255, 255]]
+    r, d = fr.threshold(g, t + 0.7, 200.4, 0)
+    assert r == float(t) and d.tolist() == [[0, 0, 0, 200, 200]]
+
+
+def test_open_keeps_runs_of_29():
+    # open((15,1), it=2) == erode 29 then dilate 29: keeps horizontal runs >= 29
+    img = np.zeros((5, 200), np.uint8)
+    img[1, 10:38] = 255  # 28 long -> removed
+    img[3, 10:39] = 255  # 29 long -> kept
+    out = fr.morphology_ex(img, 2, (15, 1), iterations=2)
+    assert out[1].sum() == 0
+    assert np.array_equal(out[3], img[3])
+    # a run touching the border counts outside pixels as foreground for the erosion
+    img2 = np.zeros((1, 100), np.uint8)
+    img2[0, :15] = 255
+    out2 = fr.morphology_ex(img2, 2, (15, 1), iterations=2)
+    assert np.array_equal(out2, img2)
+    img3 = np.zeros((1, 100), np.uint8)
+    img3[0, :14] = 255
+    assert fr.morphology_ex(img3, 2, (15, 1), iterations=2).sum() == 0
+
+
+def test_even_kernel_anchor():
+    # 2x2 all-ones, anchor (1,1): window offsets {-1, 0}
+    img = np.zeros((5, 5), np.uint8)
+    img[2, 2] = 255
+    d = fr.morphology_ex(img, 1, (2, 2))
+    exp = np.zeros((5, 5), np.uint8)
+    exp[2:4, 2:4] = 255
+    assert np.array_equal(d, exp)
+    e = fr.morphology_ex(255 - img, 0, (2, 2))
+    assert np.array_equal(e, 255 - exp)
+
+
+def test_gaussian_5x5_impulse():
+    img = np.zeros((9, 9), np.uint8)
+    img[4, 4] = 255
+    out = fr.gaussian_blur(img, (5, 5), 0)
+    k = np.array([1, 4, 6, 4, 1])
+    exp = (np.outer(k, k) * 255 + 128) >> 8
+    assert np.array_equal(out[2:7, 2:7], exp)
+    assert np.array_equal(fr.gaussian_kernel_q8(5, 0), [16, 64, 96, 64, 16])
+    assert fr.gaussian_kernel_q8(5, 1.0).sum() == 256
+
+
+def test_canny_vertical_step():
+    g = np.zeros((8, 12), np.uint8)
+    g[:, 6:] = 255
+    e = fr.canny(g, 50, 150)
+    # |dx| = 1020 on columns 5 and 6; NMS keeps m > left && m >= right -> column 5 only
+    exp = np.zeros_like(g)
+    exp[:, 5] = 255
+    assert np.array_equal(e, exp)
+
+
+def test_canny_weak_chain_needs_a_seed():
+    # horizontal ramp giving magnitude between low and high: weak only -> nothing survives
+    g = np.zeros((8, 12), np.uint8)
+    g[:, 6:] = 20  # |dx| = 80: 50 < 80 <= 150
+    assert fr.canny(g, 50, 150).sum() == 0
+    g2 = g.copy()
+    g2[:4, 6:] = 255  # top half strong, bottom half weak but connected
+    e = fr.canny(g2, 50, 150)
+    # rows 5..7 have magnitude 80 only (weak) yet survive through the chain to the strong top half
+    assert (e[5:, 5] == 255).all() and (e[:3, 5] == 255).all()
+
+
+def test_hough_single_pixel_and_line():
+    img = np.zeros((40, 60), np.uint8)
+    img[7, 11] = 255
+    acc = fr.hough_accum(img, 1, np.pi / 180)
+    na, nrho = acc.shape[0] - 2, acc.shape[1] - 2
+    assert (na, nrho) == (180, 201)
+    assert acc.sum() == 180 and acc.max() == 1
+    assert acc[1, 11 + (nrho - 1) // 2 + 1] == 1  # theta 0: rho = x
+    assert acc[91, 7 + (nrho - 1) // 2 + 1] == 1  # theta 90 deg: rho = y
+    img[:] = 0
+    img[20, 5:55] = 255
+    lines = fr.hough_lines(img, 1, np.pi / 180, 40)
+    assert lines is not None
+    rho, theta = lines[0, 0]
+    assert rho == 20.0 and theta == np.float32(90) * np.float32(np.pi / 180)
+    assert fr.hough_lines(np.zeros((10, 10), np.uint8), 1, np.pi / 180, 2) is None
+
+
+def test_otsu_bimodal():
+    g = np.concatenate([np.full(500, 40, np.uint8), np.full(300, 200, np.uint8)]).reshape(20, 40)
+    r, d = fr.threshold(g, 0, 255, 8)
+    assert r == 40.0  # first strict maximum of the between-class variance
+    assert nr.otsu(g) == 40
+    assert d.sum() == 300 * 255
+
+
+# ---------------------------------------------------------------- restatement
+def _rand_imgs():
+    rng = np.random.default_rng(7)
+    yield rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    yield (rng.random((64, 131)) < 0.3).astype(np.uint8) * 255
+    sm = ndimage.uniform_filter(rng.integers(0, 256, (90, 77)).astype(np.float32), 5)
+    yield sm.astype(np.uint8)
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+@pytest.mark.parametrize("ks,it", [((3, 3), 1), ((3, 3), 2), ((15, 1), 2), ((1, 15), 2), ((2, 2), 1), ((4, 3), 2), ((1, 1), 3), ((5, 7), 0)])
+def test_morph_c_vs_numpy(op, ks, it):
+    for img in _rand_imgs():
+        assert np.array_equal(fr.morphology_ex(img, op, ks, it), nr.morph(img, op, ks, it))
+
+
+def test_blur_c_vs_numpy():
+    for img in _rand_imgs():
+        assert np.array_equal(fr.gaussian_blur(img, (5, 5), 0), nr.gaussian_blur_5x5_sigma0(img))
+        assert np.array_equal(fr.gaussian_blur(img, (3, 3), 0), nr.gaussian_blur_3x3_sigma0(img))
+
+
+def test_canny_c_vs_numpy(cd_bgr, login_bgr):
+    imgs = list(_rand_imgs()) + [fr.bgr2gray(cd_bgr), fr.bgr2gray(login_bgr)[:300, :400]]
+    for g in imgs:
+        for lo, hi in [(50, 150), (50, 50), (200, 100)]:
+            e, m = fr.canny(g, lo, hi, return_map=True)
+            assert np.array_equal(m, nr.canny_map(g, lo, hi))
+            assert np.array_equal(e, nr.canny(g, lo, hi))
+
+
+def test_hough_c_vs_numpy(cd_bgr):
+    e = fr.canny(fr.bgr2gray(cd_bgr), 50, 150)
+    acc = fr.hough_accum(e, 1, np.pi / 180)
+    assert np.array_equal(acc, nr.hough_accum(e, 1, np.pi / 180))
+    assert acc.sum() == 180 * np.count_nonzero(e)
+    for thr in (2, 60):
+        a, b = fr.hough_lines(e, 1, np.pi / 180, thr), nr.hough_lines(e, 1, np.pi / 180, thr)
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_adaptive_c_vs_numpy():
+    for img in _rand_imgs():
+        for typ in (0, 1):
+            for block in (3, 11, 31):
+                assert np.array_equal(fr.adaptive_threshold(img, 255, 1, typ, block, 2),
+                                      nr.adaptive_threshold_gaussian_ref(img, 255, typ, block, 2))
+                assert np.array_equal(fr.adaptive_threshold(img, 255, 0, typ, block, 2),
+                                      nr.adaptive_threshold_mean_ref(img, 255, typ, block, 2))
+
+
+def test_otsu_c_vs_numpy(cd_bgr):
+    for img in list(_rand_imgs()) + [fr.bgr2gray(cd_bgr)]:
+        assert fr.threshold(img, 0, 255, 8)[0] == nr.otsu(img)
+        t, d = fr.threshold(img, 0, 255, 9)
+        assert np.array_equal(d, nr.threshold(img, 0, 255, 9)[1])
