@@ -1,0 +1,115 @@
+// Library-level entry points: version, error text, pitch helper and the fused
+// front-end that chains the per-op launchers on one stream.
+#include "common.hpp"
+
+#include <math.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void ipa_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+IPA_EXPORT int ipa_version(void) { return 100; }
+IPA_EXPORT const char* ipa_last_error(void) { return g_err; }
+IPA_EXPORT size_t ipa_pitch_for(size_t row_bytes) { return align_up(row_bytes ? row_bytes : 1, 256); }
+
+int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, int32_t* vmax,
+                     hipStream_t st);
+int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, void* ws, size_t ws_bytes, hipStream_t st);
+
+namespace {
+struct FrontWs {
+    size_t bits_bytes, canny_bytes, hough_bytes, blur_ws_bytes, blur_plane_bytes, blur_pitch;
+};
+FrontWs front_layout(int w, int h, int batch, int max_points)
+{
+    FrontWs L;
+    L.bits_bytes = bits_pitch_words(w) * 4 * (size_t)h * batch;
+    L.canny_bytes = canny_ws_bytes(w, h, batch);
+    L.hough_bytes = hough_ws_bytes(w, h, batch, max_points);
+    L.blur_ws_bytes = ipa_gaussian_blur_workspace_bytes(w, h, batch);
+    L.blur_pitch = align_up((size_t)w, 256);
+    L.blur_plane_bytes = L.blur_pitch * (size_t)h * batch;
+    return L;
+}
+}  // namespace
+
+IPA_EXPORT size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points)
+{
+    if (width <= 0 || height <= 0 || batch <= 0) return 0;
+    FrontWs L = front_layout(width, height, batch, max_points);
+    Arena a(nullptr, 0);
+    a.take(L.bits_bytes);
+    a.take(L.canny_bytes);
+    a.take(L.hough_bytes);
+    a.take(L.blur_ws_bytes);
+    a.take(L.blur_plane_bytes);
+    return a.off + 256;
+}
+
+IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
+                                uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch,
+                                size_t plane_stride, int32_t* accum, size_t accum_stride, int max_points,
+                                int32_t* point_counts, int width, int height, int batch, int thresh_val, int vert_len,
+                                int horiz_len, int iterations, double canny_lo, double canny_hi, int blur5x5, void* ws,
+                                size_t ws_bytes, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(vert_len >= 1 && horiz_len >= 1 && iterations >= 1, IPA_ERR_ARG,
+                "front_end: vert_len, horiz_len and iterations must be >= 1");
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Plane B = mkplane(bgr, bgr_pitch, bgr_stride);
+    Plane G = mkplane(gray, plane_pitch, plane_stride), T = mkplane(thresh, plane_pitch, plane_stride);
+    Plane V = mkplane(vlines, plane_pitch, plane_stride), H = mkplane(hlines, plane_pitch, plane_stride);
+    Plane E = mkplane(edges, plane_pitch, plane_stride);
+    IPA_REQUIRE(plane_ok(B, (size_t)width * 3, batch), IPA_ERR_ALIGN, "front_end: bgr pointer/pitch misaligned");
+    IPA_REQUIRE(plane_ok(G, (size_t)width, batch) && plane_ok(T, (size_t)width, batch) &&
+                    plane_ok(V, (size_t)width, batch) && plane_ok(H, (size_t)width, batch) &&
+                    plane_ok(E, (size_t)width, batch),
+                IPA_ERR_ALIGN, "front_end: output plane pointer/pitch misaligned");
+    IPA_REQUIRE(!accum || point_counts, IPA_ERR_ARG, "front_end: point_counts is NULL");
+    IPA_REQUIRE(ws && ws_bytes >= ipa_front_end_workspace_bytes(width, height, batch, max_points), IPA_ERR_WORKSPACE,
+                "front_end: workspace too small");
+    FrontWs L = front_layout(width, height, batch, max_points);
+    Arena ar(ws, ws_bytes);
+    u32* bits = (u32*)ar.take(L.bits_bytes);
+    void* canny_ws = ar.take(L.canny_bytes);
+    void* hough_ws = ar.take(L.hough_bytes);
+    void* blur_ws = ar.take(L.blur_ws_bytes);
+    u8* blur_plane = (u8*)ar.take(L.blur_plane_bytes);
+    const size_t bpw = bits_pitch_words(width), bsw = bpw * (size_t)height;
+    int tv = thresh_val < -1 ? -1 : (thresh_val > 256 ? 256 : thresh_val);
+
+    // gray + THRESH_BINARY_INV plane + its bit plane, one pass over the BGR input
+    int rc = launch_bgr2gray(B, G, T, bits, bpw, bsw, width, height, batch, tv, 255, 1, st);
+    if (rc) return rc;
+    // open with (1 x vert_len) and (horiz_len x 1), iterations folded into one larger kernel
+    const int KV = vert_len + (iterations - 1) * (vert_len - 1), AV = (vert_len / 2) * iterations;
+    const int KH = horiz_len + (iterations - 1) * (horiz_len - 1), AH = (horiz_len / 2) * iterations;
+    rc = launch_bitmorph(bits, bpw, bsw, V, width, height, batch, 0, 2, 1, KV, 0, AV, 255, nullptr, st);
+    if (rc) return rc;
+    rc = launch_bitmorph(bits, bpw, bsw, H, width, height, batch, 0, 2, KH, 1, AH, 0, 255, nullptr, st);
+    if (rc) return rc;
+    Plane csrc = G;
+    if (blur5x5) {
+        Plane BL = mkplane(blur_plane, L.blur_pitch, L.blur_pitch * (size_t)height);
+        rc = launch_gauss5(G, BL, width, height, batch, blur_ws, L.blur_ws_bytes, st);
+        if (rc) return rc;
+        csrc = BL;
+    }
+    double lo = canny_lo, hi = canny_hi;
+    if (lo > hi) { double t = lo; lo = hi; hi = t; }
+    rc = run_canny(csrc, E, width, height, batch, (int)floor(lo), (int)floor(hi), canny_ws, L.canny_bytes, st);
+    if (rc) return rc;
+    if (accum)
+        rc = run_hough_accum(E, width, height, batch, 1.0, M_PI / 180, accum, accum_stride, max_points, point_counts,
+                             hough_ws, L.hough_bytes, st);
+    return rc;
+}

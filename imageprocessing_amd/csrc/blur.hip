@@ -1,0 +1,366 @@
+// GaussianBlur (8-bit fixed point, as OpenCV's 8u path) and adaptiveThreshold
+// (float32 Gaussian mean or integer box mean, then a signed compare).
+//
+// Separable: a row pass into a 16-bit (Q8.8) / 32-bit intermediate held in the
+// caller's workspace, then a column pass that finishes the pixel.  Each lane
+// produces 4 adjacent pixels.  Built with -ffp-contract=off: the float path
+// must round every multiply and add on its own.
+#include "common.hpp"
+
+#include <math.h>
+
+namespace {
+
+#define IPA_MAX_TAPS 127
+
+struct Taps {
+    int n;
+    int border;
+    int16_t q8[IPA_MAX_TAPS + 1];  // Q0.8 taps, sum 256
+};
+
+struct TapsF {
+    int n;
+    float f[IPA_MAX_TAPS + 1];
+};
+
+// cv::borderInterpolate for REPLICATE(1) / REFLECT(2) / REFLECT_101(4); CONSTANT(0) -> -1
+__device__ __forceinline__ int border_idx(int p, int len, int type)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (type == 1) return p < 0 ? 0 : len - 1;
+    if (type == 2 || type == 4) {
+        int delta = type == 4;
+        if (len == 1) return 0;
+        do {
+            if (p < 0) p = -p - 1 + delta;
+            else p = len - 1 - (p - len) - delta;
+        } while ((unsigned)p >= (unsigned)len);
+        return p;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_gauss_row(Plane src, u16* __restrict__ tmp, size_t tpitch, size_t tstride,
+                                                   int w, int h, int quads, long long total, Taps T)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int r = T.n >> 1;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int qx = (int)(c % quads);
+        long long t = c / quads;
+        int y = (int)(t % h), b = (int)(t / h);
+        const u8* s = src.row(b, y);
+        u32 acc[4] = {0, 0, 0, 0};
+        const int x0 = qx * 4;
+        for (int i = 0; i < T.n + 3; i++) {
+            int xi = border_idx(x0 + i - r, w, T.border);
+            u32 p = xi < 0 ? 0u : s[xi];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i >= q && i < T.n + q) acc[q] += p * (u32)T.q8[i - q];
+        }
+        u16* o = tmp + (size_t)b * tstride + (size_t)y * tpitch + x0;
+        u32 lo = min(acc[0], 65535u) | (min(acc[1], 65535u) << 16);
+        u32 hi = min(acc[2], 65535u) | (min(acc[3], 65535u) << 16);
+        *(uint2*)o = make_uint2(lo, hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gauss_col(const u16* __restrict__ tmp, size_t tpitch, size_t tstride,
+                                                   Plane dst, int w, int h, int quads, long long total, Taps T)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int r = T.n >> 1;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int qx = (int)(c % quads);
+        long long t = c / quads;
+        int y = (int)(t % h), b = (int)(t / h);
+        u32 acc[4] = {0, 0, 0, 0};
+        for (int i = 0; i < T.n; i++) {
+            int yi = border_idx(y + i - r, h, T.border);
+            if (yi < 0) continue;
+            uint2 v = *(const uint2*)(tmp + (size_t)b * tstride + (size_t)yi * tpitch + qx * 4);
+            u32 k = (u32)T.q8[i];
+            acc[0] += k * (v.x & 0xffffu);
+            acc[1] += k * (v.x >> 16);
+            acc[2] += k * (v.y & 0xffffu);
+            acc[3] += k * (v.y >> 16);
+        }
+        u32 o = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) o |= min((acc[q] + 32768u) >> 16, 255u) << (8 * q);
+        *(u32*)(dst.row(b, y) + qx * 4) = o;
+    }
+}
+
+// ---- adaptive threshold ----------------------------------------------------
+// row pass: float Gaussian (taps accumulated left to right) or integer box sums
+template <bool GAUSS>
+__global__ __launch_bounds__(256) void k_adapt_row(Plane src, u32* __restrict__ tmp, size_t tpitch, size_t tstride,
+                                                   int w, int h, int quads, long long total, TapsF T)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int r = T.n >> 1;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int qx = (int)(c % quads);
+        long long t = c / quads;
+        int y = (int)(t % h), b = (int)(t / h);
+        const u8* s = src.row(b, y);
+        const int x0 = qx * 4;
+        float fa[4] = {0.f, 0.f, 0.f, 0.f};
+        u32 ia[4] = {0, 0, 0, 0};
+        for (int i = 0; i < T.n + 3; i++) {
+            int xi = border_idx(x0 + i - r, w, 1);
+            u32 p = s[xi];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i >= q && i < T.n + q) {
+                    if (GAUSS) {
+                        float prod = __fmul_rn((float)p, T.f[i - q]);
+                        fa[q] = __fadd_rn(fa[q], prod);
+                    } else {
+                        ia[q] += p;
+                    }
+                }
+        }
+        u32* o = tmp + (size_t)b * tstride + (size_t)y * tpitch + x0;
+        if (GAUSS)
+            *(uint4*)o = make_uint4(__float_as_uint(fa[0]), __float_as_uint(fa[1]), __float_as_uint(fa[2]),
+                                    __float_as_uint(fa[3]));
+        else
+            *(uint4*)o = make_uint4(ia[0], ia[1], ia[2], ia[3]);
+    }
+}
+
+// column pass + compare.  tab semantics: BINARY: src - mean > -idelta ; INV: src - mean <= -idelta
+template <bool GAUSS>
+__global__ __launch_bounds__(256) void k_adapt_col(Plane src, const u32* __restrict__ tmp, size_t tpitch,
+                                                   size_t tstride, Plane dst, int w, int h, int quads, long long total,
+                                                   TapsF T, double box_scale, int idelta, int inv, u32 maxv)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int r = T.n >> 1;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int qx = (int)(c % quads);
+        long long t = c / quads;
+        int y = (int)(t % h), b = (int)(t / h);
+        const u32* base = tmp + (size_t)b * tstride + qx * 4;
+        int mean[4];
+        if (GAUSS) {
+            uint4 c0 = *(const uint4*)(base + (size_t)y * tpitch);
+            float acc[4] = {__fmul_rn(T.f[r], __uint_as_float(c0.x)), __fmul_rn(T.f[r], __uint_as_float(c0.y)),
+                            __fmul_rn(T.f[r], __uint_as_float(c0.z)), __fmul_rn(T.f[r], __uint_as_float(c0.w))};
+            for (int i = 1; i <= r; i++) {
+                uint4 a = *(const uint4*)(base + (size_t)border_idx(y + i, h, 1) * tpitch);
+                uint4 d = *(const uint4*)(base + (size_t)border_idx(y - i, h, 1) * tpitch);
+                float k = T.f[r + i];
+                acc[0] = __fadd_rn(acc[0], __fmul_rn(k, __fadd_rn(__uint_as_float(a.x), __uint_as_float(d.x))));
+                acc[1] = __fadd_rn(acc[1], __fmul_rn(k, __fadd_rn(__uint_as_float(a.y), __uint_as_float(d.y))));
+                acc[2] = __fadd_rn(acc[2], __fmul_rn(k, __fadd_rn(__uint_as_float(a.z), __uint_as_float(d.z))));
+                acc[3] = __fadd_rn(acc[3], __fmul_rn(k, __fadd_rn(__uint_as_float(a.w), __uint_as_float(d.w))));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int v = __float2int_rn(acc[q]);
+                mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+        } else {
+            u32 acc[4] = {0, 0, 0, 0};
+            for (int i = -r; i <= r; i++) {
+                uint4 a = *(const uint4*)(base + (size_t)border_idx(y + i, h, 1) * tpitch);
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int v = (int)rint((double)acc[q] * box_scale);
+                mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+        }
+        u32 sv = *(const u32*)(src.row(b, y) + qx * 4);
+        u32 o = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int d = (int)((sv >> (8 * q)) & 0xffu) - mean[q];
+            bool on = inv ? (d <= -idelta) : (d > -idelta);
+            o |= (on ? maxv : 0u) << (8 * q);
+        }
+        *(u32*)(dst.row(b, y) + qx * 4) = o;
+    }
+}
+
+// ---- host-side tap tables (cv::getGaussianKernel and its Q0.8 form) ---------
+void gaussian_taps_f64(int n, double sigma, double* k)
+{
+    static const double tab1[] = {1.0};
+    static const double tab3[] = {0.25, 0.5, 0.25};
+    static const double tab5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    static const double tab7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    if ((n & 1) && n <= 7 && sigma <= 0) {
+        const double* f = n == 1 ? tab1 : n == 3 ? tab3 : n == 5 ? tab5 : tab7;
+        for (int i = 0; i < n; i++) k[i] = f[i];
+        return;
+    }
+    double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2 = -0.5 / (sx * sx), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        k[i] = exp(scale2 * x * x);
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] *= sum;
+}
+
+// Q0.8 taps summing to 256: exact tables for sigma <= 0 and small n, otherwise
+// quantised from the outside in, carrying the rounding error, centre = remainder.
+void gaussian_taps_q8(int n, double sigma, int16_t* q)
+{
+    if (sigma <= 0 && n == 9) {
+        static const int16_t t9[] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
+        for (int i = 0; i < 9; i++) q[i] = t9[i];
+        return;
+    }
+    double kd[IPA_MAX_TAPS + 1];
+    gaussian_taps_f64(n, sigma, kd);
+    if (sigma <= 0 && (n & 1) && n <= 7) {
+        for (int i = 0; i < n; i++) q[i] = (int16_t)lrint(kd[i] * 256.0);
+        return;
+    }
+    int n2 = n / 2;
+    double err = 0;
+    long long sum = 0;
+    for (int i = 0; i < n2; i++) {
+        double adj = kd[i] * 256.0 + err;
+        long long v = llrint(adj);
+        err = adj - (double)v;
+        q[i] = q[n - 1 - i] = (int16_t)v;
+        sum += v;
+    }
+    q[n2] = (int16_t)(256 - 2 * sum);
+}
+
+size_t tmp_pitch_elems(int w) { return align_up((size_t)w, 64); }
+
+}  // namespace
+
+IPA_EXPORT size_t ipa_gaussian_blur_workspace_bytes(int width, int height, int batch)
+{
+    if (width <= 0 || height <= 0 || batch <= 0) return 0;
+    return align_up(tmp_pitch_elems(width) * sizeof(u16) * (size_t)height * batch, 256) + 256;
+}
+
+static int gaussian_impl(Plane s, Plane d, int width, int height, int batch, int kw, int kh, double sigma_x,
+                         double sigma_y, int border, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    if (sigma_y <= 0) sigma_y = sigma_x;
+    if (kw <= 0 && sigma_x > 0) kw = (int)lrint(sigma_x * 3 * 2 + 1) | 1;
+    if (kh <= 0 && sigma_y > 0) kh = (int)lrint(sigma_y * 3 * 2 + 1) | 1;
+    IPA_REQUIRE(kw > 0 && (kw & 1) && kh > 0 && (kh & 1), IPA_ERR_ARG,
+                "GaussianBlur: ksize.width > 0 && ksize.width %% 2 == 1 && ksize.height > 0 && ksize.height %% 2 == 1");
+    IPA_REQUIRE(kw <= IPA_MAX_TAPS && kh <= IPA_MAX_TAPS, IPA_ERR_ARG, "GaussianBlur: kernel larger than %d taps",
+                IPA_MAX_TAPS);
+    IPA_REQUIRE(border == 0 || border == 1 || border == 2 || border == 4, IPA_ERR_ARG,
+                "GaussianBlur: unsupported borderType %d", border);
+    IPA_REQUIRE(ws && ws_bytes >= ipa_gaussian_blur_workspace_bytes(width, height, batch), IPA_ERR_WORKSPACE,
+                "GaussianBlur: workspace too small");
+    Taps tx, ty;
+    tx.n = kw; ty.n = kh; tx.border = ty.border = border;
+    gaussian_taps_q8(kw, sigma_x > 0 ? sigma_x : 0, tx.q8);
+    gaussian_taps_q8(kh, sigma_y > 0 ? sigma_y : 0, ty.q8);
+    Arena ar(ws, ws_bytes);
+    size_t tp = tmp_pitch_elems(width);
+    u16* tmp = (u16*)ar.take(tp * sizeof(u16) * (size_t)height * batch);
+    int quads = cdiv(width, 4);
+    long long total = (long long)quads * height * batch;
+    unsigned grid = stream_grid(total, 256);
+    hipLaunchKernelGGL(k_gauss_row, dim3(grid), dim3(256), 0, st, s, tmp, tp, tp * (size_t)height, width, height,
+                       quads, total, tx);
+    IPA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gauss_col, dim3(grid), dim3(256), 0, st, (const u16*)tmp, tp, tp * (size_t)height, d, width,
+                       height, quads, total, ty);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_gaussian_blur_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst,
+                                    size_t dst_pitch, size_t dst_stride, int width, int height, int batch, int kw,
+                                    int kh, double sigma_x, double sigma_y, int border, void* ws, size_t ws_bytes,
+                                    void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK;
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "GaussianBlur: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    return gaussian_impl(s, d, width, height, batch, kw, kh, sigma_x, sigma_y, border, ws, ws_bytes,
+                         (hipStream_t)stream);
+}
+
+// 5x5, sigma 0, REFLECT_101 blur used by the fused front-end (variant with blur).
+int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    return gaussian_impl(src, dst, w, h, batch, 5, 5, 0, 0, IPA_BORDER_REFLECT_101, ws, ws_bytes, st);
+}
+
+IPA_EXPORT size_t ipa_adaptive_threshold_workspace_bytes(int width, int height, int batch)
+{
+    if (width <= 0 || height <= 0 || batch <= 0) return 0;
+    return align_up(tmp_pitch_elems(width) * sizeof(u32) * (size_t)height * batch, 256) + 256;
+}
+
+IPA_EXPORT int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst,
+                                         size_t dst_pitch, size_t dst_stride, int width, int height, int batch,
+                                         double max_value, int method, int type, int block_size, double c, void* ws,
+                                         size_t ws_bytes, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(block_size % 2 == 1 && block_size > 1, IPA_ERR_ARG,
+                "adaptiveThreshold: blockSize %% 2 == 1 && blockSize > 1");
+    IPA_REQUIRE(method == 0 || method == 1, IPA_ERR_ARG, "adaptiveThreshold: unknown adaptive method");
+    IPA_REQUIRE(type == 0 || type == 1, IPA_ERR_ARG, "adaptiveThreshold: unknown threshold type");
+    IPA_REQUIRE(block_size <= IPA_MAX_TAPS, IPA_ERR_ARG, "adaptiveThreshold: blockSize larger than %d", IPA_MAX_TAPS);
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "adaptiveThreshold: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    if (max_value < 0) {
+        IPA_HIP(hipMemset2DAsync(dst, dst_pitch, 0, (size_t)width, (size_t)height, st));
+        for (int b = 1; b < batch; b++)
+            IPA_HIP(hipMemset2DAsync(dst + (size_t)b * dst_stride, dst_pitch, 0, (size_t)width, (size_t)height, st));
+        return IPA_OK;
+    }
+    IPA_REQUIRE(ws && ws_bytes >= ipa_adaptive_threshold_workspace_bytes(width, height, batch), IPA_ERR_WORKSPACE,
+                "adaptiveThreshold: workspace too small");
+    TapsF T;
+    T.n = block_size;
+    double kd[IPA_MAX_TAPS + 1];
+    gaussian_taps_f64(block_size, 0.0, kd);
+    for (int i = 0; i < block_size; i++) T.f[i] = (float)kd[i];
+    size_t tp = tmp_pitch_elems(width);
+    u32* tmp = (u32*)ws;
+    int quads = cdiv(width, 4);
+    long long total = (long long)quads * height * batch;
+    unsigned grid = stream_grid(total, 256);
+    long mvl = lrint(max_value);
+    u32 maxv = (u32)(mvl < 0 ? 0 : (mvl > 255 ? 255 : mvl));
+    int idelta = type == 0 ? (int)ceil(c) : (int)floor(c);
+    double box_scale = 1.0 / ((double)block_size * block_size);
+    if (method == 1) {
+        hipLaunchKernelGGL((k_adapt_row<true>), dim3(grid), dim3(256), 0, st, s, tmp, tp, tp * (size_t)height, width,
+                           height, quads, total, T);
+        IPA_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_adapt_col<true>), dim3(grid), dim3(256), 0, st, s, (const u32*)tmp, tp,
+                           tp * (size_t)height, d, width, height, quads, total, T, box_scale, idelta, type, maxv);
+    } else {
+        hipLaunchKernelGGL((k_adapt_row<false>), dim3(grid), dim3(256), 0, st, s, tmp, tp, tp * (size_t)height, width,
+                           height, quads, total, T);
+        IPA_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_adapt_col<false>), dim3(grid), dim3(256), 0, st, s, (const u32*)tmp, tp,
+                           tp * (size_t)height, d, width, height, quads, total, T, box_scale, idelta, type, maxv);
+    }
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}

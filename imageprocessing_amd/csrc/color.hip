@@ -1,0 +1,462 @@
+// Streaming per-pixel kernels: BGR->gray (optionally fused with the binary
+// threshold and a 1-bit-per-pixel copy of it), channel shuffles, bitwise ops,
+// fixed / Otsu thresholds and the 256-bin histogram.
+//
+// Every kernel moves 16 pixels per lane with 16-byte accesses; a wave64 touches
+// 1 KiB (gray) or 3 KiB (BGR) of contiguous memory per row segment.
+#include "common.hpp"
+
+#include <float.h>
+
+namespace {
+
+__device__ __forceinline__ u32 byte_of(const u32* d, int k) { return (d[k >> 2] >> (8 * (k & 3))) & 0xffu; }
+
+// OpenCV 4.x 8-bit BGR2GRAY: Q15 coefficients, round to nearest.
+__device__ __forceinline__ u32 luma(u32 b, u32 g, u32 r) { return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15; }
+
+// ---------------------------------------------------------------------------
+// BGR -> gray [, thresholded plane][, bit plane].  One lane = one 16-pixel chunk
+// (48 input bytes).  `cpr` = chunks per row, rounded up to an even number so
+// that lanes 2k / 2k+1 of a wave always hold the two halves of one 32-bit word
+// of the bit plane.
+template <bool THRESH, bool PACK>
+__global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* __restrict__ bits,
+                                                  size_t bpw, size_t bsw, int w, int h, int cpr, long long total,
+                                                  int ithresh, u32 v_above, u32 v_below)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < total; base += step) {
+        const long long c = base + threadIdx.x;
+        u32 mybits = 0;
+        int cx = 0, y = 0, b = 0;
+        bool live = c < total;
+        if (live) {
+            cx = (int)(c % cpr);
+            long long t = c / cpr;
+            y = (int)(t % h);
+            b = (int)(t / h);
+            live = cx * 16 < w;
+        }
+        if (live) {
+            const u8* s = bgr.row(b, y) + (size_t)cx * 48;
+            u8* gd = gray.row(b, y) + (size_t)cx * 16;
+            if (cx * 16 + 16 <= w) {
+                u32 d[12];
+                const uint4* s4 = (const uint4*)s;
+                uint4 a0 = s4[0], a1 = s4[1], a2 = s4[2];
+                d[0] = a0.x; d[1] = a0.y; d[2] = a0.z; d[3] = a0.w;
+                d[4] = a1.x; d[5] = a1.y; d[6] = a1.z; d[7] = a1.w;
+                d[8] = a2.x; d[9] = a2.y; d[10] = a2.z; d[11] = a2.w;
+                u32 g[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    u32 v = luma(byte_of(d, 3 * i), byte_of(d, 3 * i + 1), byte_of(d, 3 * i + 2));
+                    g[i >> 2] |= v << (8 * (i & 3));
+                    if (THRESH) {
+                        bool above = (int)v > ithresh;
+                        t[i >> 2] |= (above ? v_above : v_below) << (8 * (i & 3));
+                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << i;
+                    }
+                }
+                *(uint4*)gd = make_uint4(g[0], g[1], g[2], g[3]);
+                if (THRESH) *(uint4*)(bin.row(b, y) + (size_t)cx * 16) = make_uint4(t[0], t[1], t[2], t[3]);
+            } else {
+                const int n = w - cx * 16;
+                u8* td = THRESH ? bin.row(b, y) + (size_t)cx * 16 : nullptr;
+                for (int i = 0; i < n; i++) {
+                    u32 v = luma(s[3 * i], s[3 * i + 1], s[3 * i + 2]);
+                    gd[i] = (u8)v;
+                    if (THRESH) {
+                        bool above = (int)v > ithresh;
+                        td[i] = (u8)(above ? v_above : v_below);
+                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << i;
+                    }
+                }
+            }
+        }
+        if (PACK) {
+            // all 64 lanes reach this shuffle: the loop bounds are wave-uniform
+            u32 other = __shfl_xor(mybits, 1);
+            if (c < total && !(threadIdx.x & 1)) {
+                int cx0 = (int)(c % cpr);
+                long long t = c / cpr;
+                int yy = (int)(t % h), bb = (int)(t / h);
+                bits[(size_t)bb * bsw + (size_t)yy * bpw + (cx0 >> 1)] = mybits | (other << 16);
+            }
+        }
+    }
+}
+
+// gray -> BGR (replicate) : 16 px per lane, 16 B in, 48 B out.
+__global__ __launch_bounds__(256) void k_gray2bgr(Plane gray, Plane bgr, int w, int h, int cpr, long long total)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int cx = (int)(c % cpr);
+        long long t = c / cpr;
+        int y = (int)(t % h), b = (int)(t / h);
+        const u8* s = gray.row(b, y) + (size_t)cx * 16;
+        u8* o = bgr.row(b, y) + (size_t)cx * 48;
+        if (cx * 16 + 16 <= w) {
+            uint4 a = *(const uint4*)s;
+            u32 d[4] = {a.x, a.y, a.z, a.w};
+            u32 r[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) r[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 48; k++) r[k >> 2] |= byte_of(d, k / 3) << (8 * (k & 3));
+            uint4* o4 = (uint4*)o;
+            o4[0] = make_uint4(r[0], r[1], r[2], r[3]);
+            o4[1] = make_uint4(r[4], r[5], r[6], r[7]);
+            o4[2] = make_uint4(r[8], r[9], r[10], r[11]);
+        } else {
+            int n = w - cx * 16;
+            for (int i = 0; i < n; i++) o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = s[i];
+        }
+    }
+}
+
+// swap channels 0 and 2 of an interleaved 3-channel image.
+__global__ __launch_bounds__(256) void k_swap_rb(Plane src, Plane dst, int w, int h, int cpr, long long total)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int cx = (int)(c % cpr);
+        long long t = c / cpr;
+        int y = (int)(t % h), b = (int)(t / h);
+        const u8* s = src.row(b, y) + (size_t)cx * 48;
+        u8* o = dst.row(b, y) + (size_t)cx * 48;
+        if (cx * 16 + 16 <= w) {
+            const uint4* s4 = (const uint4*)s;
+            uint4 a0 = s4[0], a1 = s4[1], a2 = s4[2];
+            u32 d[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+            u32 r[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) r[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 48; k++) r[k >> 2] |= byte_of(d, k - (k % 3) + (2 - k % 3)) << (8 * (k & 3));
+            uint4* o4 = (uint4*)o;
+            o4[0] = make_uint4(r[0], r[1], r[2], r[3]);
+            o4[1] = make_uint4(r[4], r[5], r[6], r[7]);
+            o4[2] = make_uint4(r[8], r[9], r[10], r[11]);
+        } else {
+            int n = w - cx * 16;
+            for (int i = 0; i < n; i++) {
+                u8 c0 = s[3 * i], c1 = s[3 * i + 1], c2 = s[3 * i + 2];
+                o[3 * i] = c2; o[3 * i + 1] = c1; o[3 * i + 2] = c0;
+            }
+        }
+    }
+}
+
+// Element-wise byte kernels over `rb` bytes per row (rb = width * channels).
+// MODE 0: dst = src > t ? hi : lo (t read from `tdev[b]` when non-null)
+// MODE 1: dst = ~src        MODE 2: dst = src | src2
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bytewise(Plane src, Plane src2, Plane dst, int rb, int h, int cpr,
+                                                  long long total, int ithresh, const int32_t* __restrict__ tdev,
+                                                  u32 v_above, u32 v_below)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int cx = (int)(c % cpr);
+        long long t = c / cpr;
+        int y = (int)(t % h), b = (int)(t / h);
+        // reading / writing the whole 16-byte chunk is safe: pitch is a multiple of 16
+        uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
+        u32 d[4] = {a.x, a.y, a.z, a.w}, r[4];
+        if (MODE == 0) {
+            int th = tdev ? tdev[b] : ithresh;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int v = (d[k] >> (8 * j)) & 0xff;
+                    o |= (v > th ? v_above : v_below) << (8 * j);
+                }
+                r[k] = o;
+            }
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = ~d[k];
+        } else {
+            uint4 e = *(const uint4*)(src2.row(b, y) + (size_t)cx * 16);
+            r[0] = d[0] | e.x; r[1] = d[1] | e.y; r[2] = d[2] | e.z; r[3] = d[3] | e.w;
+        }
+        *(uint4*)(dst.row(b, y) + (size_t)cx * 16) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// 256-bin histogram.  Each wave keeps a private LDS histogram.  A white page is
+// ~97 % one value, so the common case is a wave whose 1024 pixels are all equal:
+// that is detected with a wave vote and costs one LDS atomic instead of 1024.
+__global__ __launch_bounds__(256) void k_hist(Plane src, int w, int h, int cpr, long long chunks_per_img,
+                                              u32* __restrict__ hist)
+{
+    __shared__ u32 lh[4][256];
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < chunks_per_img; base += step) {
+        long long c = base + threadIdx.x;
+        int n = 0;
+        u32 d[4] = {0, 0, 0, 0};
+        if (c < chunks_per_img) {
+            int cx = (int)(c % cpr), y = (int)(c / cpr);
+            n = min(16, w - cx * 16);
+            uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+        }
+        u32 first = d[0] & 0xffu;
+        u32 rep = first * 0x01010101u;
+        bool same = n == 16 && d[0] == rep && d[1] == rep && d[2] == rep && d[3] == rep;
+        u32 lead = __shfl(first, 0);
+        if (__all(same && first == lead)) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&lh[wave][lead], 1024u);
+        } else {
+            // merge runs of equal bytes before touching LDS
+            u32 cur = first, run = 0;
+            for (int i = 0; i < n; i++) {
+                u32 v = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                if (v == cur) {
+                    run++;
+                } else {
+                    atomicAdd(&lh[wave][cur], run);
+                    cur = v;
+                    run = 1;
+                }
+            }
+            if (run) atomicAdd(&lh[wave][cur], run);
+        }
+    }
+    __syncthreads();
+    u32 s = lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
+    if (s) atomicAdd(&hist[(size_t)b * 256 + threadIdx.x], s);
+}
+
+// Otsu's threshold from a 256-bin histogram: OpenCV's sequential scan in double
+// precision (one lane per image; 256 steps).
+__global__ void k_otsu_scan(const u32* __restrict__ hist, int batch, long long npix, int32_t* __restrict__ out)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const u32* hgram = hist + (size_t)b * 256;
+    double mu = 0, scale = 1.0 / (double)npix;
+    for (int i = 0; i < 256; i++) mu += i * (double)hgram[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0;
+    int max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        double p_i = hgram[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        double q2 = 1. - q1;
+        if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        double mu2 = (mu - q1 * mu1) / q2;
+        double d = mu1 - mu2;
+        double sigma = q1 * q2 * d * d;
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
+    }
+    out[b] = max_val;
+}
+
+int sat_u8_round(double v)
+{
+    long r = lrint(v);
+    return (int)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+}  // namespace
+
+int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch,
+                    int ithresh, int maxval, int inv, hipStream_t st)
+{
+    int cpr = cdiv(w, 16);
+    cpr += cpr & 1;
+    long long total = (long long)cpr * h * batch;
+    if (total == 0) return IPA_OK;
+    unsigned grid = stream_grid(total, 256);
+    u32 va = inv ? 0u : (u32)maxval, vb = inv ? (u32)maxval : 0u;
+    // the bit plane holds "pixel is non-zero in the thresholded plane"
+    if (bin.p && bits)
+        hipLaunchKernelGGL((k_bgr2gray<true, true>), dim3(grid), dim3(256), 0, st, bgr, gray, bin, bits, bpw, bsw, w, h,
+                           cpr, total, ithresh, va, vb);
+    else if (bin.p)
+        hipLaunchKernelGGL((k_bgr2gray<true, false>), dim3(grid), dim3(256), 0, st, bgr, gray, bin, bits, bpw, bsw, w,
+                           h, cpr, total, ithresh, va, vb);
+    else
+        hipLaunchKernelGGL((k_bgr2gray<false, false>), dim3(grid), dim3(256), 0, st, bgr, gray, bin, bits, bpw, bsw, w,
+                           h, cpr, total, ithresh, va, vb);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+#define CHECK_DIMS()                                                                          \
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size"); \
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK
+
+IPA_EXPORT int ipa_bgr2gray_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
+                               size_t gray_pitch, size_t gray_stride, int width, int height, int batch, void* stream)
+{
+    CHECK_DIMS();
+    Plane s = mkplane(bgr, bgr_pitch, bgr_stride), d = mkplane(gray, gray_pitch, gray_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width * 3, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "bgr2gray: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    return launch_bgr2gray(s, d, mkplane(nullptr, 0, 0), nullptr, 0, 0, width, height, batch, 0, 0, 0,
+                           (hipStream_t)stream);
+}
+
+IPA_EXPORT int ipa_gray2bgr_u8(const uint8_t* gray, size_t gray_pitch, size_t gray_stride, uint8_t* bgr,
+                               size_t bgr_pitch, size_t bgr_stride, int width, int height, int batch, void* stream)
+{
+    CHECK_DIMS();
+    Plane s = mkplane(gray, gray_pitch, gray_stride), d = mkplane(bgr, bgr_pitch, bgr_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width * 3, batch), IPA_ERR_ALIGN,
+                "gray2bgr: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    int cpr = cdiv(width, 16);
+    long long total = (long long)cpr * height * batch;
+    hipLaunchKernelGGL(k_gray2bgr, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s, d, width,
+                       height, cpr, total);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_swap_rb_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
+                              size_t dst_stride, int width, int height, int batch, void* stream)
+{
+    CHECK_DIMS();
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width * 3, batch) && plane_ok(d, (size_t)width * 3, batch), IPA_ERR_ALIGN,
+                "swap_rb: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    int cpr = cdiv(width, 16);
+    long long total = (long long)cpr * height * batch;
+    hipLaunchKernelGGL(k_swap_rb, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s, d, width,
+                       height, cpr, total);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_bitwise_not_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst,
+                                  size_t dst_pitch, size_t dst_stride, int row_bytes, int height, int batch,
+                                  void* stream)
+{
+    int width = row_bytes;
+    CHECK_DIMS();
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)row_bytes, batch) && plane_ok(d, (size_t)row_bytes, batch), IPA_ERR_ALIGN,
+                "bitwise_not: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    int cpr = cdiv(row_bytes, 16);
+    long long total = (long long)cpr * height * batch;
+    hipLaunchKernelGGL((k_bytewise<1>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s, s, d,
+                       row_bytes, height, cpr, total, 0, (const int32_t*)nullptr, 0u, 0u);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_bitwise_or_u8(const uint8_t* a, size_t a_pitch, size_t a_stride, const uint8_t* b, size_t b_pitch,
+                                 size_t b_stride, uint8_t* dst, size_t dst_pitch, size_t dst_stride, int row_bytes,
+                                 int height, int batch, void* stream)
+{
+    int width = row_bytes;
+    CHECK_DIMS();
+    Plane s = mkplane(a, a_pitch, a_stride), s2 = mkplane(b, b_pitch, b_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)row_bytes, batch) && plane_ok(s2, (size_t)row_bytes, batch) &&
+                    plane_ok(d, (size_t)row_bytes, batch),
+                IPA_ERR_ALIGN, "bitwise_or: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    int cpr = cdiv(row_bytes, 16);
+    long long total = (long long)cpr * height * batch;
+    hipLaunchKernelGGL((k_bytewise<2>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s, s2, d,
+                       row_bytes, height, cpr, total, 0, (const int32_t*)nullptr, 0u, 0u);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+static int threshold_impl(Plane s, Plane d, int width, int height, int batch, int ithresh, const int32_t* tdev,
+                          double maxval, int type, hipStream_t st)
+{
+    IPA_REQUIRE(type == IPA_THRESH_BINARY || type == IPA_THRESH_BINARY_INV, IPA_ERR_ARG,
+                "threshold: only THRESH_BINARY / THRESH_BINARY_INV (optionally with THRESH_OTSU) are supported");
+    int mv = sat_u8_round(maxval);
+    u32 va = type == IPA_THRESH_BINARY ? (u32)mv : 0u, vb = type == IPA_THRESH_BINARY ? 0u : (u32)mv;
+    int cpr = cdiv(width, 16);
+    long long total = (long long)cpr * height * batch;
+    hipLaunchKernelGGL((k_bytewise<0>), dim3(stream_grid(total, 256)), dim3(256), 0, st, s, s, d, width, height, cpr,
+                       total, ithresh, tdev, va, vb);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_threshold_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst,
+                                size_t dst_pitch, size_t dst_stride, int width, int height, int batch, double thresh,
+                                double maxval, int type, void* stream)
+{
+    CHECK_DIMS();
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "threshold: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    double f = floor(thresh);
+    int ithresh = f < -1 ? -1 : (f > 256 ? 256 : (int)f);
+    return threshold_impl(s, d, width, height, batch, ithresh, nullptr, maxval, type, (hipStream_t)stream);
+}
+
+static int histogram_impl(Plane s, int width, int height, int batch, u32* hist, hipStream_t st)
+{
+    IPA_HIP(hipMemsetAsync(hist, 0, (size_t)batch * 256 * sizeof(u32), st));
+    int cpr = cdiv(width, 16);
+    long long cpi = (long long)cpr * height;
+    unsigned gx = (unsigned)((cpi + 256 * 8 - 1) / (256 * 8));
+    unsigned cap = (unsigned)(4096 / (batch < 4096 ? batch : 4096));
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        Plane sb = s;
+        sb.p += (size_t)b0 * s.stride;
+        hipLaunchKernelGGL(k_hist, dim3(gx, nb), dim3(256), 0, st, sb, width, height, cpr, cpi, hist + (size_t)b0 * 256);
+        IPA_LAUNCH_CHECK();
+    }
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_histogram_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, int width, int height,
+                                int batch, uint32_t* hist, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(hist != nullptr, IPA_ERR_ARG, "histogram: hist is NULL");
+    if (width == 0 || height == 0) {
+        IPA_HIP(hipMemsetAsync(hist, 0, (size_t)batch * 256 * sizeof(u32), (hipStream_t)stream));
+        return IPA_OK;
+    }
+    Plane s = mkplane(src, src_pitch, src_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
+                "histogram: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    return histogram_impl(s, width, height, batch, hist, (hipStream_t)stream);
+}
+
+IPA_EXPORT int ipa_threshold_otsu_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst,
+                                     size_t dst_pitch, size_t dst_stride, int width, int height, int batch,
+                                     double maxval, int type, uint32_t* hist, int32_t* otsu, void* stream)
+{
+    CHECK_DIMS();
+    IPA_REQUIRE(hist && otsu, IPA_ERR_ARG, "threshold_otsu: hist/otsu buffers are NULL");
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "threshold_otsu: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = histogram_impl(s, width, height, batch, hist, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_otsu_scan, dim3(cdiv(batch, 64)), dim3(64), 0, st, hist, batch, (long long)width * height,
+                       otsu);
+    IPA_LAUNCH_CHECK();
+    return threshold_impl(s, d, width, height, batch, 0, otsu, maxval, type & 7, st);
+}

@@ -1,0 +1,123 @@
+// Shared host/device helpers for the gfx950 raster front-end kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ipamd.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define IPA_EXPORT extern "C" __attribute__((visibility("default")))
+
+// One 8-bit plane (or interleaved 3-channel image) of a batch in device memory.
+struct Plane {
+    u8* p;
+    size_t pitch;   // bytes between rows
+    size_t stride;  // bytes between images
+    __host__ __device__ u8* row(int b, int y) const { return p + (size_t)b * stride + (size_t)y * pitch; }
+};
+
+static inline Plane mkplane(const void* p, size_t pitch, size_t stride)
+{
+    Plane r;
+    r.p = (u8*)p;
+    r.pitch = pitch;
+    r.stride = stride;
+    return r;
+}
+
+void ipa_set_error(const char* fmt, ...);
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+static inline bool plane_ok(const Plane& pl, size_t row_bytes, int batch)
+{
+    if (!pl.p || !aligned16(pl.p)) return false;
+    if (pl.pitch % 16 || pl.pitch < row_bytes) return false;
+    if (batch > 1 && (pl.stride % 16)) return false;
+    return true;
+}
+
+#define IPA_REQUIRE(cond, code, ...)          \
+    do {                                      \
+        if (!(cond)) {                        \
+            ipa_set_error(__VA_ARGS__);       \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+#define IPA_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            ipa_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return IPA_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define IPA_LAUNCH_CHECK()                                                              \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            ipa_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return IPA_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Grid for a flat streaming kernel: enough blocks to fill 256 CUs several times
+// over, grid-striding beyond that.
+static inline unsigned stream_grid(long long items, int block)
+{
+    long long g = (items + block - 1) / block;
+    const long long cap = 256LL * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// Bump allocator over the caller's workspace.
+struct Arena {
+    u8* base;
+    size_t size;
+    size_t off;
+    Arena(void* p, size_t n) : base((u8*)p), size(n), off(0) {}
+    void* take(size_t n)
+    {
+        off = align_up(off, 256);
+        void* r = base ? base + off : nullptr;
+        off += n;
+        return r;
+    }
+    bool ok() const { return off <= size; }
+};
+
+// ---- internal entry points shared between translation units --------------
+// (all enqueue on `st`; no validation: callers have validated)
+int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bits_pitch_words, size_t bits_stride_words,
+                    int w, int h, int batch, int ithresh, int maxval, int inv, hipStream_t st);
+
+// bit-plane geometry: words per row rounded to a multiple of 4 (16 bytes)
+static inline size_t bits_pitch_words(int w) { return align_up((size_t)cdiv(w, 32), 4); }
+
+int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, hipStream_t st);
+int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, int h, int batch, int first_is_dilate,
+                    int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st);
+int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batch, int is_dilate, int kx, int ky,
+                         int ax, int ay, hipStream_t st);
+int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, hipStream_t st);
+
+size_t canny_ws_bytes(int w, int h, int batch);
+int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
+              hipStream_t st);
+
+size_t hough_ws_bytes(int w, int h, int batch, int max_points);
+int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
+                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1,0 +1,375 @@
+// Standard Hough line transform (OpenCV HoughLinesStandard semantics).
+//
+//  k_hough_compact : edge plane -> per-image list of non-zero pixels (y<<16 | x),
+//                    one global atomic per workgroup pass (block-wide scan).
+//  k_hough_vote    : LDS-privatised voting.  A workgroup owns a few consecutive
+//                    angles (and, for huge images, a slice of the rho axis) of
+//                    ONE image; only the rho bins an angle can reach for this
+//                    image size live in LDS.  It streams the image's point list,
+//                    votes with LDS atomics, then writes its accumulator rows to
+//                    global memory exactly once (zeros included, so no memset).
+//  k_hough_peaks   : 4-neighbour local maxima above the threshold -> 64-bit keys.
+//
+// rho = round_half_even(x*cos + y*sin) with float32 multiply/add rounded
+// separately (the file is built with -ffp-contract=off and uses __fmul_rn /
+// __fadd_rn), matching a scalar SSE build of OpenCV.
+#include "common.hpp"
+
+#include <math.h>
+
+namespace {
+
+#define IPA_MAX_ANGLES 448
+
+struct Trig {
+    float s[IPA_MAX_ANGLES];
+    float c[IPA_MAX_ANGLES];
+};
+
+__global__ __launch_bounds__(256) void k_hough_compact(Plane src, int w, int h, int cpr, long long chunks_per_img,
+                                                       u32* __restrict__ pts, size_t pts_stride, u32 cap,
+                                                       int32_t* __restrict__ counts)
+{
+    __shared__ u32 wave_tot[4];
+    __shared__ u32 s_base;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* out = pts + (size_t)b * pts_stride;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < chunks_per_img; base += step) {
+        long long c = base + tid;
+        u32 d[4] = {0, 0, 0, 0};
+        int n = 0, cx = 0, y = 0;
+        if (c < chunks_per_img) {
+            cx = (int)(c % cpr);
+            y = (int)(c / cpr);
+            n = min(16, w - cx * 16);
+            uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+        }
+        u32 mask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (i < n && ((d[i >> 2] >> (8 * (i & 3))) & 0xffu)) mask |= 1u << i;
+        u32 cnt = __popc(mask);
+        // inclusive scan over the wave
+        u32 scan = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u32 t = __shfl_up(scan, o);
+            if (lane >= o) scan += t;
+        }
+        if (lane == 63) wave_tot[wave] = scan;
+        __syncthreads();
+        u32 before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 t = wave_tot[k];
+            if (k < wave) before += t;
+            total += t;
+        }
+        if (tid == 0) s_base = total ? (u32)atomicAdd(&counts[b], (int32_t)total) : 0u;
+        __syncthreads();
+        u32 pos = s_base + before + scan - cnt;
+        u32 xy = ((u32)y << 16) | (u32)(cx * 16);
+        while (mask) {
+            int i = __ffs(mask) - 1;
+            mask &= mask - 1;
+            if (pos < cap) out[pos] = xy + (u32)i;
+            pos++;
+        }
+        __syncthreads();  // wave_tot / s_base reused next round
+    }
+}
+
+struct VoteArgs {
+    const u32* pts;
+    size_t pts_stride;
+    u32 cap;
+    const int32_t* counts;
+    int32_t* accum;
+    size_t accum_stride;
+    int w, h, numangle, numrho;
+    int tg;        // number of angles owned by one workgroup
+    int groups;    // ceil(numangle / tg)
+    int nseg;      // slices of the padded rho axis
+    int seg_cols;  // columns (of numrho+2) per slice
+    int span_max;  // LDS bins per angle
+};
+
+__device__ __forceinline__ int rho_index(float x, float y, float c, float s)
+{
+    return __float2int_rn(__fadd_rn(__fmul_rn(x, c), __fmul_rn(y, s)));
+}
+
+__global__ __launch_bounds__(256) void k_hough_vote(VoteArgs A, Trig T)
+{
+    extern __shared__ __align__(16) u32 hist[];
+    __shared__ int s_col0[64];  // first padded column held in LDS, per angle of the group
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int grp = blockIdx.x / A.nseg, seg = blockIdx.x % A.nseg;
+    const int n0 = grp * A.tg;
+    const int tg = min(A.tg, A.numangle - n0);
+    const int half = (A.numrho - 1) / 2;
+    const int seg_lo = seg * A.seg_cols, seg_hi = min(seg_lo + A.seg_cols, A.numrho + 2);
+
+    if (tid < tg) {
+        // smallest reachable rho for this angle: the float ops are monotone, so
+        // the extreme lies at a corner of the image
+        float c = T.c[n0 + tid], s = T.s[n0 + tid];
+        float xw = (float)(A.w - 1), yh = (float)(A.h - 1);
+        int r00 = rho_index(0.f, 0.f, c, s), r10 = rho_index(xw, 0.f, c, s);
+        int r01 = rho_index(0.f, yh, c, s), r11 = rho_index(xw, yh, c, s);
+        int rmin = min(min(r00, r10), min(r01, r11));
+        int col0 = rmin + half + 1;  // padded column of rmin
+        s_col0[tid] = max(col0, seg_lo);
+    }
+    for (int i = tid; i < tg * A.span_max; i += 256) hist[i] = 0;
+    __syncthreads();
+
+    const u32 npts = min((u32)A.counts[b], A.cap);
+    const u32* pts = A.pts + (size_t)b * A.pts_stride;
+    for (u32 i = tid; i < npts; i += 256) {
+        u32 p = pts[i];
+        float x = (float)(p & 0xffffu), y = (float)(p >> 16);
+        for (int g = 0; g < tg; g++) {
+            int col = rho_index(x, y, T.c[n0 + g], T.s[n0 + g]) + half + 1;
+            int idx = col - s_col0[g];
+            if (col < seg_hi && (unsigned)idx < (unsigned)A.span_max) atomicAdd(&hist[g * A.span_max + idx], 1u);
+        }
+    }
+    __syncthreads();
+
+    // write this workgroup's slice of its accumulator rows (+ the two border rows)
+    int32_t* acc = A.accum + (size_t)b * A.accum_stride;
+    const int ncols = A.numrho + 2;
+    for (int g = 0; g < tg; g++) {
+        int32_t* row = acc + (size_t)(n0 + g + 1) * ncols;
+        const int c0 = s_col0[g];
+        for (int col = seg_lo + tid; col < seg_hi; col += 256) {
+            int idx = col - c0;
+            row[col] = ((unsigned)idx < (unsigned)A.span_max) ? (int32_t)hist[g * A.span_max + idx] : 0;
+        }
+    }
+    if (grp == 0)
+        for (int col = seg_lo + tid; col < seg_hi; col += 256) acc[col] = 0;
+    if (grp == A.groups - 1)
+        for (int col = seg_lo + tid; col < seg_hi; col += 256) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__ accum, size_t accum_stride,
+                                                     int numangle, int numrho, int threshold,
+                                                     u64* __restrict__ keys, int capacity,
+                                                     int32_t* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int32_t* acc = accum + (size_t)b * accum_stride;
+    const int ncols = numrho + 2;
+    const long long cells = (long long)numangle * numrho;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < cells; base += step) {
+        long long i = base + threadIdx.x;
+        bool peak = false;
+        int v = 0;
+        long long idx = 0;
+        if (i < cells) {
+            int n = (int)(i / numrho), r = (int)(i - (long long)n * numrho);
+            idx = (long long)(n + 1) * ncols + r + 1;
+            v = acc[idx];
+            if (v > threshold)
+                peak = v > acc[idx - 1] && v >= acc[idx + 1] && v > acc[idx - ncols] && v >= acc[idx + ncols];
+        }
+        unsigned long long m = __ballot(peak);
+        if (m) {
+            int leader = __ffsll((long long)m) - 1;
+            int32_t basepos = 0;
+            if (lane == leader) basepos = atomicAdd(&counts[b], (int32_t)__popcll(m));
+            basepos = __shfl(basepos, leader);
+            if (peak) {
+                int pos = basepos + (int)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < capacity)
+                    keys[(size_t)b * capacity + pos] = ((u64)(u32)v << 32) | (u64)(0xffffffffu - (u32)idx);
+            }
+        }
+    }
+}
+
+void hough_dims(int w, int h, double rho, double theta, int* numangle, int* numrho)
+{
+    float frho = (float)rho, ftheta = (float)theta;
+    int max_rho = w + h, min_rho = -max_rho;
+    int na = (int)floor((M_PI - 0.0) / ftheta) + 1;
+    if (na > 1 && fabs(M_PI - (na - 1) * ftheta) < ftheta / 2) --na;
+    *numangle = na;
+    *numrho = (int)lrint(((max_rho - min_rho) + 1) / frho);
+}
+
+bool g_vote_attr_set = false;
+
+}  // namespace
+
+IPA_EXPORT int ipa_hough_dims(int width, int height, double rho, double theta, int* numangle, int* numrho)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(rho > 0 && theta > 0, IPA_ERR_ARG, "HoughLines: rho and theta must be positive");
+    IPA_REQUIRE(numangle && numrho, IPA_ERR_ARG, "HoughLines: NULL output");
+    hough_dims(width, height, rho, theta, numangle, numrho);
+    return IPA_OK;
+}
+
+static u32 point_cap(int w, int h, int max_points)
+{
+    long long full = (long long)w * h;
+    if (max_points > 0 && max_points < full) return (u32)max_points;
+    return (u32)(full > 0xffffffffLL ? 0xffffffffLL : full);
+}
+
+size_t hough_ws_bytes(int w, int h, int batch, int max_points)
+{
+    if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    return align_up((size_t)point_cap(w, h, max_points) * 4, 256) * (size_t)batch + 256;
+}
+
+int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
+                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    IPA_REQUIRE(w <= 65535 && h <= 65535, IPA_ERR_ARG, "HoughLines: image larger than 65535 pixels on a side");
+    int numangle, numrho;
+    hough_dims(w, h, rho, theta, &numangle, &numrho);
+    IPA_REQUIRE(numangle >= 1 && numangle <= IPA_MAX_ANGLES, IPA_ERR_ARG,
+                "HoughLines: %d angles (theta too small; at most %d supported)", numangle, IPA_MAX_ANGLES);
+    IPA_REQUIRE(numrho >= 1, IPA_ERR_ARG, "HoughLines: rho too large");
+    IPA_REQUIRE(accum_stride >= (size_t)(numangle + 2) * (numrho + 2) || batch == 1, IPA_ERR_ARG,
+                "HoughLines: accumulator stride too small");
+    IPA_REQUIRE(ws && ws_bytes >= hough_ws_bytes(w, h, batch, max_points), IPA_ERR_WORKSPACE,
+                "HoughLines: workspace too small");
+    const u32 cap = point_cap(w, h, max_points);
+    const size_t pts_stride = align_up((size_t)cap * 4, 256) / 4;
+    u32* pts = (u32*)ws;
+
+    Trig T;
+    {
+        float frho = (float)rho, ftheta = (float)theta;
+        float irho = 1 / frho;
+        float ang = 0.f;
+        for (int n = 0; n < numangle; ang += ftheta, n++) {
+            T.s[n] = (float)(sin((double)ang) * irho);
+            T.c[n] = (float)(cos((double)ang) * irho);
+        }
+    }
+    IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+    {
+        int cpr = cdiv(w, 16);
+        long long cpi = (long long)cpr * h;
+        unsigned gx = (unsigned)((cpi + 255) / 256);
+        unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
+        if (capx < 1) capx = 1;
+        if (gx > capx) gx = capx;
+        for (int b0 = 0; b0 < batch; b0 += 65535) {
+            int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            Plane sb = src;
+            sb.p += (size_t)b0 * src.stride;
+            hipLaunchKernelGGL(k_hough_compact, dim3(gx, nb), dim3(256), 0, st, sb, w, h, cpr, cpi,
+                               pts + (size_t)b0 * pts_stride, pts_stride, cap, point_counts + b0);
+            IPA_LAUNCH_CHECK();
+        }
+    }
+    // geometry of the vote kernel
+    VoteArgs A;
+    A.pts = pts; A.pts_stride = pts_stride; A.cap = cap; A.counts = point_counts;
+    A.accum = accum; A.accum_stride = accum_stride;
+    A.w = w; A.h = h; A.numangle = numangle; A.numrho = numrho;
+    // bins an angle can reach: |x cos| + |y sin| <= (w-1 + h-1) / rho, plus rounding slack
+    long long reach = (long long)ceil(((double)(w - 1) + (double)(h - 1)) / rho) + 3;
+    double diag = ceil(sqrt((double)(w - 1) * (w - 1) + (double)(h - 1) * (h - 1)) / rho) + 3;
+    if (diag < (double)reach) reach = (long long)diag;
+    const int ncols = numrho + 2;
+    if (reach > ncols) reach = ncols;
+    const long long lds_budget_bins = (150 * 1024) / 4;  // up to 150 KiB of LDS per workgroup
+    if (reach <= lds_budget_bins) {
+        A.nseg = 1;
+        A.span_max = (int)reach;
+        A.seg_cols = ncols;
+    } else {
+        // one angle's bins do not fit: slice the padded rho axis
+        A.nseg = cdiv(ncols, lds_budget_bins);
+        A.seg_cols = cdiv(ncols, A.nseg);
+        A.span_max = A.seg_cols;
+    }
+    // several angles per workgroup (~48 KiB of LDS) when there are plenty of workgroups anyway
+    int tg = (int)((48 * 1024 / 4) / A.span_max);
+    if (tg < 1) tg = 1;
+    if (tg > 8) tg = 8;
+    while (tg > 1 && (long long)cdiv(numangle, tg) * batch < 2048) tg--;
+    A.tg = tg;
+    A.groups = cdiv(numangle, tg);
+    size_t lds = (size_t)tg * A.span_max * 4;
+    if (lds > 48 * 1024 && !g_vote_attr_set) {
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        g_vote_attr_set = true;
+    }
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        VoteArgs Ab = A;
+        Ab.pts = pts + (size_t)b0 * pts_stride;
+        Ab.counts = point_counts + b0;
+        Ab.accum = accum + (size_t)b0 * accum_stride;
+        hipLaunchKernelGGL(k_hough_vote, dim3((unsigned)(A.groups * A.nseg), nb), dim3(256), lds, st, Ab, T);
+        IPA_LAUNCH_CHECK();
+    }
+    return IPA_OK;
+}
+
+IPA_EXPORT size_t ipa_hough_workspace_bytes(int width, int height, int batch, int max_points)
+{
+    return hough_ws_bytes(width, height, batch, max_points);
+}
+
+IPA_EXPORT int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, int width, int height,
+                                  int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
+                                  int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(rho > 0 && theta > 0, IPA_ERR_ARG, "HoughLines: rho and theta must be positive");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(accum && point_counts, IPA_ERR_ARG, "HoughLines: NULL accumulator / counts");
+    hipStream_t st = (hipStream_t)stream;
+    if (width == 0 || height == 0) {
+        int na, nr;
+        hough_dims(width, height, rho, theta, &na, &nr);
+        for (int b = 0; b < batch; b++)
+            IPA_HIP(hipMemsetAsync(accum + (size_t)b * accum_stride, 0, sizeof(int32_t) * (size_t)(na + 2) * (nr + 2), st));
+        IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+        return IPA_OK;
+    }
+    Plane s = mkplane(src, src_pitch, src_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
+                "HoughLines: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    return run_hough_accum(s, width, height, batch, rho, theta, accum, accum_stride, max_points, point_counts, ws,
+                           ws_bytes, st);
+}
+
+IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle, int numrho, int batch,
+                                   int threshold, uint64_t* keys, int capacity, int32_t* peak_counts, void* stream)
+{
+    IPA_REQUIRE(numangle >= 1 && numrho >= 1 && batch >= 0 && capacity >= 0, IPA_ERR_ARG, "HoughLines: bad peak arguments");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(accum && peak_counts && (keys || capacity == 0), IPA_ERR_ARG, "HoughLines: NULL peak buffers");
+    hipStream_t st = (hipStream_t)stream;
+    IPA_HIP(hipMemsetAsync(peak_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+    long long cells = (long long)numangle * numrho;
+    unsigned gx = (unsigned)((cells + 255) / 256);
+    unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
+    if (capx < 1) capx = 1;
+    if (gx > capx) gx = capx;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(k_hough_peaks, dim3(gx, nb), dim3(256), 0, st, accum + (size_t)b0 * accum_stride,
+                           accum_stride, numangle, numrho, threshold, (u64*)keys + (size_t)b0 * capacity, capacity,
+                           peak_counts + b0);
+        IPA_LAUNCH_CHECK();
+    }
+    return IPA_OK;
+}

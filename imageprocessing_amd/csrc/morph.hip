@@ -1,0 +1,524 @@
+// Rectangular erode / dilate / open / close.
+//
+// Two families of kernels:
+//  * bit-plane kernels for two-valued images (the thresholded planes of the
+//    diagram parsers): the image is packed to 1 bit per pixel, a tile of it is
+//    held in LDS, and a k-long min/max becomes log2(k)+1 shifted AND/OR steps on
+//    32-pixel words (rows: funnel shifts, columns: whole-word row offsets).  Both
+//    stages of an open/close run on the tile without leaving LDS; the result is
+//    expanded back to bytes on the way out (16 pixels per 16-byte store).
+//  * general 8-bit kernels (any gray levels): separable row / column passes.
+//
+// Semantics (OpenCV): window of output x is input [x-ax, x-ax+k-1]; samples
+// outside the image are ignored; iterations of an all-ones kernel fold into one
+// pass with k' = k + (n-1)(k-1), a' = a*n.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ bit planes
+
+// 8-bit plane -> bit plane (bit = pixel != 0), plus the largest pixel value of
+// each image (the common non-zero value when the image is two-valued).
+__global__ __launch_bounds__(256) void k_pack_bits(Plane src, u32* __restrict__ bits, size_t bpw, size_t bsw, int w,
+                                                   int h, int cpr, long long total, int32_t* __restrict__ vmax)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < total; base += step) {
+        const long long c = base + threadIdx.x;
+        u32 mybits = 0, mx = 0;
+        int cx = 0, y = 0, b = 0;
+        if (c < total) {
+            cx = (int)(c % cpr);
+            long long t = c / cpr;
+            y = (int)(t % h);
+            b = (int)(t / h);
+            int n = min(16, w - cx * 16);
+            if (n > 0) {
+                uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
+                u32 d[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    u32 v = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    if (i < n && v) {
+                        mybits |= 1u << i;
+                        mx = max(mx, v);
+                    }
+                }
+            }
+        }
+        u32 other = __shfl_xor(mybits, 1);
+        if (c < total && !(threadIdx.x & 1)) bits[(size_t)b * bsw + (size_t)y * bpw + (cx >> 1)] = mybits | (other << 16);
+        if (mx && (u32)vmax[b] < mx) atomicMax(&vmax[b], (int32_t)mx);
+    }
+}
+
+// Two-valued test: flags[b] = common non-zero value, 0 (all zero) or -1.
+__global__ __launch_bounds__(256) void k_binary_check(Plane src, int w, int h, int cpr, long long total,
+                                                      int32_t* __restrict__ flags)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int cx = (int)(c % cpr);
+        long long t = c / cpr;
+        int y = (int)(t % h), b = (int)(t / h);
+        int n = min(16, w - cx * 16);
+        uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
+        u32 d[4] = {a.x, a.y, a.z, a.w};
+        for (int i = 0; i < n; i++) {
+            int v = (d[i >> 2] >> (8 * (i & 3))) & 0xff;
+            if (!v) continue;
+            int cur = flags[b];
+            if (cur == v || cur == -1) continue;
+            int old = atomicCAS(&flags[b], 0, v);
+            if (old != 0 && old != v) atomicExch(&flags[b], -1);
+        }
+    }
+}
+
+struct BitMorphArgs {
+    const u32* bits;
+    size_t bpw, bsw;  // words per row / per image of the bit plane
+    Plane dst;
+    int w, h;
+    int tww, tr;    // output tile: words x rows
+    int hlw, hrw;   // halo words left / right
+    int ht, hb;     // halo rows top / bottom
+    int tiles_x, tiles_y;
+    int first_is_dilate, nops;
+    int kx, ky, ax, ay;
+    int px, py;     // largest power of two <= kx / ky
+    int value;
+    const int32_t* value_dev;  // per-image value (overrides `value` when non-null)
+};
+
+// 32 bits of row `row` (RW words) starting at bit position `pos` (may lie outside).
+__device__ __forceinline__ u32 rd_bits(const u32* row, int RW, int pos, u32 ident)
+{
+    int wi = pos >> 5;
+    u32 s = (u32)pos & 31u;
+    u32 lo = (wi >= 0 && wi < RW) ? row[wi] : ident;
+    u32 hi = (wi + 1 >= 0 && wi + 1 < RW) ? row[wi + 1] : ident;
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+}
+
+__device__ __forceinline__ u32 comb(u32 a, u32 b, bool dil) { return dil ? (a | b) : (a & b); }
+
+// One workgroup = one output tile of one image.  LDS: two ping-pong copies of
+// the tile plus halo, RR rows x RW words each.
+__global__ __launch_bounds__(256) void k_bitmorph(BitMorphArgs A)
+{
+    extern __shared__ __align__(16) u32 lds[];
+    const int RW = A.tww + A.hlw + A.hrw;
+    const int RR = A.tr + A.ht + A.hb;
+    const int N = RW * RR;
+    u32* cur = lds;
+    u32* nxt = lds + N;
+    const int tid = threadIdx.x;
+    int tile = blockIdx.x;
+    const int tx = tile % A.tiles_x;
+    tile /= A.tiles_x;
+    const int ty = tile % A.tiles_y;
+    const int b = tile / A.tiles_y;
+    const int gw0 = tx * A.tww - A.hlw;  // global word index of region word 0
+    const int gy0 = ty * A.tr - A.ht;    // global row of region row 0
+    const int words_in_row = (A.w + 31) >> 5;
+    const u32* img = A.bits + (size_t)b * A.bsw;
+
+    // in-image mask of region word (r, j)
+    auto inside_mask = [&](int r, int j) -> u32 {
+        int gy = gy0 + r;
+        if (gy < 0 || gy >= A.h) return 0u;
+        int gx = (gw0 + j) * 32;
+        if (gx + 32 <= 0 || gx >= A.w) return 0u;
+        if (gx < 0) return 0u;  // word-aligned: a word is never partly left of the image
+        int rem = A.w - gx;
+        return rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+    };
+
+    bool dil = A.first_is_dilate != 0;
+    u32 ident = dil ? 0u : 0xffffffffu;
+    for (int e = tid; e < N; e += 256) {
+        int r = e / RW, j = e - r * RW;
+        int gy = gy0 + r, gj = gw0 + j;
+        u32 v = 0;
+        if (gy >= 0 && gy < A.h && gj >= 0 && gj < words_in_row) v = img[(size_t)gy * A.bpw + gj];
+        u32 m = inside_mask(r, j);
+        cur[e] = (v & m) | (ident & ~m);
+    }
+    __syncthreads();
+
+    for (int stage = 0; stage < A.nops; stage++) {
+        if (stage > 0) {
+            dil = !dil;
+            ident = dil ? 0u : 0xffffffffu;
+            // samples outside the image take the identity of the next operation
+            for (int e = tid; e < N; e += 256) {
+                int r = e / RW, j = e - r * RW;
+                u32 m = inside_mask(r, j);
+                cur[e] = (cur[e] & m) | (ident & ~m);
+            }
+            __syncthreads();
+        }
+        if (A.kx > 1) {
+            for (int m = 1; m < A.px; m <<= 1) {
+                for (int e = tid; e < N; e += 256) {
+                    int r = e / RW, j = e - r * RW;
+                    const u32* row = cur + r * RW;
+                    nxt[e] = comb(row[j], rd_bits(row, RW, 32 * j + m, ident), dil);
+                }
+                __syncthreads();
+                u32* t = cur; cur = nxt; nxt = t;
+            }
+            for (int e = tid; e < N; e += 256) {
+                int r = e / RW, j = e - r * RW;
+                const u32* row = cur + r * RW;
+                int p0 = 32 * j - A.ax;
+                nxt[e] = comb(rd_bits(row, RW, p0, ident), rd_bits(row, RW, p0 + A.kx - A.px, ident), dil);
+            }
+            __syncthreads();
+            u32* t = cur; cur = nxt; nxt = t;
+        }
+        if (A.ky > 1) {
+            for (int m = 1; m < A.py; m <<= 1) {
+                for (int e = tid; e < N; e += 256) {
+                    int r = e / RW;
+                    u32 o = (r + m < RR) ? cur[e + m * RW] : ident;
+                    nxt[e] = comb(cur[e], o, dil);
+                }
+                __syncthreads();
+                u32* t = cur; cur = nxt; nxt = t;
+            }
+            for (int e = tid; e < N; e += 256) {
+                int r = e / RW, j = e - r * RW;
+                int r0 = r - A.ay, r1 = r0 + A.ky - A.py;
+                u32 a = (r0 >= 0 && r0 < RR) ? cur[r0 * RW + j] : ident;
+                u32 c = (r1 >= 0 && r1 < RR) ? cur[r1 * RW + j] : ident;
+                nxt[e] = comb(a, c, dil);
+            }
+            __syncthreads();
+            u32* t = cur; cur = nxt; nxt = t;
+        }
+    }
+
+    // expand the tile interior to bytes: one lane = 16 pixels = one 16-byte store
+    const u32 value = A.value_dev ? (u32)A.value_dev[b] : (u32)A.value;
+    const int halves = A.tww * 2;
+    for (int e = tid; e < A.tr * halves; e += 256) {
+        int r = e / halves, hx = e - r * halves;
+        int gy = ty * A.tr + r;
+        int gx = (tx * A.tww) * 32 + hx * 16;
+        if (gy >= A.h || gx >= A.w) continue;
+        u32 wv = cur[(r + A.ht) * RW + A.hlw + (hx >> 1)];
+        u32 hbits = (wv >> ((hx & 1) * 16)) & 0xffffu;
+        u32 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 nib = (hbits >> (4 * q)) & 0xfu;
+            o[q] = ((nib * 0x00204081u) & 0x01010101u) * value;
+        }
+        *(uint4*)(A.dst.row(b, gy) + gx) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------ general 8-bit
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// per-byte min / max of two packed dwords through 16-bit packed ops
+__device__ __forceinline__ u32 minmax4(u32 a, u32 b, bool dil)
+{
+    u32 ae = a & 0x00ff00ffu, ao = (a >> 8) & 0x00ff00ffu;
+    u32 be = b & 0x00ff00ffu, bo = (b >> 8) & 0x00ff00ffu;
+    us2 xe = __builtin_bit_cast(us2, ae), ye = __builtin_bit_cast(us2, be);
+    us2 xo = __builtin_bit_cast(us2, ao), yo = __builtin_bit_cast(us2, bo);
+    us2 re = dil ? __builtin_elementwise_max(xe, ye) : __builtin_elementwise_min(xe, ye);
+    us2 ro = dil ? __builtin_elementwise_max(xo, yo) : __builtin_elementwise_min(xo, yo);
+    return __builtin_bit_cast(u32, re) | (__builtin_bit_cast(u32, ro) << 8);
+}
+
+// Row pass: a workgroup owns 1024 consecutive pixels of one row; the segment and
+// its halo sit in LDS as bytes; each lane produces 4 adjacent outputs.
+__global__ __launch_bounds__(256) void k_morph_row(Plane src, Plane dst, int w, int h, int segs, int k, int a,
+                                                   int dil)
+{
+    extern __shared__ __align__(16) u8 srow[];
+    int blk = blockIdx.x;
+    const int sx = blk % segs;
+    blk /= segs;
+    const int y = blk % h, b = blk / h;
+    const int x0 = sx * 1024;
+    const int L = (a + 3) & ~3, R = (k - 1 - a + 3) & ~3;
+    const int n = 1024 + L + R;  // bytes in LDS, multiple of 4
+    const u8 ident = dil ? 0 : 255;
+    const u8* srcrow = src.row(b, y);
+    for (int i = threadIdx.x; i < n / 4; i += 256) {
+        int gx = x0 - L + 4 * i;
+        u32 v;
+        if (gx >= 0 && gx + 4 <= w) {
+            v = *(const u32*)(srcrow + gx);
+        } else {
+            v = 0;
+            for (int j = 0; j < 4; j++) {
+                int x = gx + j;
+                u32 p = (x >= 0 && x < w) ? srcrow[x] : ident;
+                v |= p << (8 * j);
+            }
+        }
+        ((u32*)srow)[i] = v;
+    }
+    __syncthreads();
+    const int ox = x0 + 4 * threadIdx.x;
+    if (ox >= w) return;
+    const int base = L + 4 * threadIdx.x - a;
+    int o0 = ident, o1 = ident, o2 = ident, o3 = ident;
+    for (int i = 0; i < k + 3; i++) {
+        int v = srow[base + i];
+        if (dil) {
+            if (i < k) o0 = max(o0, v);
+            if (i >= 1 && i < k + 1) o1 = max(o1, v);
+            if (i >= 2 && i < k + 2) o2 = max(o2, v);
+            if (i >= 3) o3 = max(o3, v);
+        } else {
+            if (i < k) o0 = min(o0, v);
+            if (i >= 1 && i < k + 1) o1 = min(o1, v);
+            if (i >= 2 && i < k + 2) o2 = min(o2, v);
+            if (i >= 3) o3 = min(o3, v);
+        }
+    }
+    *(u32*)(dst.row(b, y) + ox) = (u32)o0 | ((u32)o1 << 8) | ((u32)o2 << 16) | ((u32)o3 << 24);
+}
+
+// Column pass: one lane = 4 adjacent columns (one dword) x 4 output rows.
+__global__ __launch_bounds__(256) void k_morph_col(Plane src, Plane dst, int w, int h, int dwords, int rowgroups, int k,
+                                                   int a, int dil, long long total)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int dx = (int)(c % dwords);
+        long long t = c / dwords;
+        int rg = (int)(t % rowgroups), b = (int)(t / rowgroups);
+        const int y0 = rg * 4;
+        const u32 ident = dil ? 0u : 0xffffffffu;
+        u32 o[4] = {ident, ident, ident, ident};
+        for (int i = 0; i < k + 3; i++) {
+            int yy = y0 - a + i;
+            if (yy < 0 || yy >= h) continue;
+            u32 v = *(const u32*)(src.row(b, yy) + 4 * dx);
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (i >= p && i < k + p) o[p] = minmax4(o[p], v, dil != 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            if (y0 + p < h) *(u32*)(dst.row(b, y0 + p) + 4 * dx) = o[p];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy_plane(Plane src, Plane dst, int cpr, int h, long long total)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        int cx = (int)(c % cpr);
+        long long t = c / cpr;
+        int y = (int)(t % h), b = (int)(t / h);
+        *(uint4*)(dst.row(b, y) + (size_t)cx * 16) = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
+    }
+}
+
+int pow2_floor(int v)
+{
+    int p = 1;
+    while (p * 2 <= v) p *= 2;
+    return p;
+}
+
+}  // namespace
+
+int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, int32_t* vmax,
+                     hipStream_t st);
+
+int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, int32_t* vmax,
+                     hipStream_t st)
+{
+    int cpr = cdiv(w, 16);
+    cpr += cpr & 1;
+    long long total = (long long)cpr * h * batch;
+    IPA_HIP(hipMemsetAsync(vmax, 0, sizeof(int32_t) * (size_t)batch, st));
+    hipLaunchKernelGGL(k_pack_bits, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, bits, bpw, bsw, w, h, cpr,
+                       total, vmax);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+// Bit-plane morphology of `nops` stages (1: erode or dilate, 2: open or close)
+// with folded kernel kx x ky and folded anchor (ax, ay).
+int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, int h, int batch, int first_is_dilate,
+                    int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st)
+{
+    BitMorphArgs A;
+    A.bits = bits; A.bpw = bpw; A.bsw = bsw; A.dst = dst; A.w = w; A.h = h;
+    A.first_is_dilate = first_is_dilate; A.nops = nops;
+    A.kx = kx; A.ky = ky; A.ax = ax; A.ay = ay;
+    A.px = pow2_floor(kx); A.py = pow2_floor(ky);
+    A.value = value; A.value_dev = value_dev;
+    // reach of the whole op sequence, per side
+    const int left = nops * ax, right = nops * (kx - 1 - ax);
+    A.hlw = kx > 1 ? cdiv(left, 32) : 0;
+    A.hrw = kx > 1 ? cdiv(right, 32) + 1 : 0;
+    A.ht = nops * ay;
+    A.hb = nops * (ky - 1 - ay);
+    const int row_words = cdiv(w, 32);
+    const int budget = 8192;  // words per LDS copy (32 KiB); two copies
+    int tww, tr;
+    if (ky == 1) {
+        // horizontal work: wide tiles, a few rows
+        tww = row_words < 256 ? row_words : 256;
+        tr = budget / (tww + A.hlw + A.hrw);
+        if (tr > 64) tr = 64;
+    } else {
+        tww = row_words < 32 ? row_words : 32;
+        if (kx > 1 && tww < 64 && row_words >= 64) tww = 64;
+        tr = budget / (tww + A.hlw + A.hrw) - A.ht - A.hb;
+    }
+    while (tr < 8 && tww > 1) {
+        tww = (tww + 1) / 2;
+        tr = budget / (tww + A.hlw + A.hrw) - A.ht - A.hb;
+    }
+    if (tr > h) tr = h;
+    if (tr < 1) {
+        ipa_set_error("morphology kernel %dx%d (iterations folded) is too large for the bit-plane tile", kx, ky);
+        return IPA_ERR_ARG;
+    }
+    A.tww = tww; A.tr = tr;
+    A.tiles_x = cdiv(row_words, tww);
+    A.tiles_y = cdiv(h, tr);
+    size_t lds = (size_t)2 * (tww + A.hlw + A.hrw) * (tr + A.ht + A.hb) * sizeof(u32);
+    long long blocks = (long long)A.tiles_x * A.tiles_y * batch;
+    if (blocks > 0x7fffffffLL) {
+        ipa_set_error("morphology: too many tiles");
+        return IPA_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_bitmorph, dim3((unsigned)blocks), dim3(256), lds, st, A);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+// One general 8-bit erode/dilate pass pair (rows then columns) with folded sizes.
+int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batch, int is_dilate, int kx, int ky,
+                         int ax, int ay, hipStream_t st)
+{
+    Plane cur = src;
+    if (kx > 1) {
+        Plane out = ky > 1 ? tmp : dst;
+        int segs = cdiv(w, 1024);
+        int L = (ax + 3) & ~3, R = (kx - 1 - ax + 3) & ~3;
+        size_t lds = (size_t)1024 + L + R;
+        if (lds > 64 * 1024) {
+            ipa_set_error("morphology: kernel width %d too large", kx);
+            return IPA_ERR_ARG;
+        }
+        long long blocks = (long long)segs * h * batch;
+        hipLaunchKernelGGL(k_morph_row, dim3((unsigned)blocks), dim3(256), lds, st, cur, out, w, h, segs, kx, ax,
+                           is_dilate);
+        IPA_LAUNCH_CHECK();
+        cur = out;
+    }
+    if (ky > 1) {
+        int dwords = cdiv(w, 4), rowgroups = cdiv(h, 4);
+        long long total = (long long)dwords * rowgroups * batch;
+        hipLaunchKernelGGL(k_morph_col, dim3(stream_grid(total, 256)), dim3(256), 0, st, cur, dst, w, h, dwords,
+                           rowgroups, ky, ay, is_dilate, total);
+        IPA_LAUNCH_CHECK();
+        cur = dst;
+    }
+    if (cur.p == src.p) {
+        int cpr = cdiv(w, 16);
+        long long total = (long long)cpr * h * batch;
+        hipLaunchKernelGGL(k_copy_plane, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, cpr, h, total);
+        IPA_LAUNCH_CHECK();
+    }
+    return IPA_OK;
+}
+
+// workspace: bit plane + per-image value + two 8-bit temporaries (general path)
+static size_t morph_tmp_pitch(int w) { return align_up((size_t)w, 256); }
+
+IPA_EXPORT size_t ipa_morph_workspace_bytes(int width, int height, int batch)
+{
+    if (width <= 0 || height <= 0 || batch <= 0) return 0;
+    Arena a(nullptr, 0);
+    a.take(bits_pitch_words(width) * 4 * (size_t)height * batch);
+    a.take(sizeof(int32_t) * (size_t)batch);
+    a.take(morph_tmp_pitch(width) * (size_t)height * batch);
+    a.take(morph_tmp_pitch(width) * (size_t)height * batch);
+    return a.off;
+}
+
+IPA_EXPORT int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, int width, int height,
+                                   int batch, int32_t* flags, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(flags != nullptr, IPA_ERR_ARG, "binary_check: flags is NULL");
+    IPA_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * (size_t)batch, (hipStream_t)stream));
+    if (width == 0 || height == 0) return IPA_OK;
+    Plane s = mkplane(src, src_pitch, src_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
+                "binary_check: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    int cpr = cdiv(width, 16);
+    long long total = (long long)cpr * height * batch;
+    hipLaunchKernelGGL(k_binary_check, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s, width,
+                       height, cpr, total, flags);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
+                            size_t dst_stride, int width, int height, int batch, int op, int kw, int kh, int anchor_x,
+                            int anchor_y, int iterations, int assume_binary, void* ws, size_t ws_bytes, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(op >= 0 && op <= 3, IPA_ERR_ARG, "morphology: op must be ERODE, DILATE, OPEN or CLOSE");
+    IPA_REQUIRE(kw >= 1 && kh >= 1, IPA_ERR_ARG, "morphology: empty structuring element");
+    IPA_REQUIRE(iterations >= 0, IPA_ERR_ARG, "morphology: negative iterations");
+    if (anchor_x < 0) anchor_x = kw / 2;
+    if (anchor_y < 0) anchor_y = kh / 2;
+    IPA_REQUIRE(anchor_x < kw && anchor_y < kh, IPA_ERR_ARG, "morphology: anchor outside the kernel");
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "morphology: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    int n = iterations;
+    if (n == 0 || (kw == 1 && kh == 1)) {
+        int cpr = cdiv(width, 16);
+        long long total = (long long)cpr * height * batch;
+        hipLaunchKernelGGL(k_copy_plane, dim3(stream_grid(total, 256)), dim3(256), 0, st, s, d, cpr, height, total);
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
+    const int KX = kw + (n - 1) * (kw - 1), KY = kh + (n - 1) * (kh - 1);
+    const int AX = anchor_x * n, AY = anchor_y * n;
+    IPA_REQUIRE(ws_bytes >= ipa_morph_workspace_bytes(width, height, batch) && ws, IPA_ERR_WORKSPACE,
+                "morphology: workspace too small");
+    Arena ar(ws, ws_bytes);
+    size_t bpw = bits_pitch_words(width);
+    size_t bsw = bpw * (size_t)height;
+    u32* bits = (u32*)ar.take(bsw * 4 * (size_t)batch);
+    int32_t* vmax = (int32_t*)ar.take(sizeof(int32_t) * (size_t)batch);
+    size_t tp = morph_tmp_pitch(width);
+    Plane t1 = mkplane(ar.take(tp * (size_t)height * batch), tp, tp * (size_t)height);
+    Plane t2 = mkplane(ar.take(tp * (size_t)height * batch), tp, tp * (size_t)height);
+    const int nops = (op == IPA_MORPH_OPEN || op == IPA_MORPH_CLOSE) ? 2 : 1;
+    const int first_dil = (op == IPA_MORPH_DILATE || op == IPA_MORPH_CLOSE) ? 1 : 0;
+    if (assume_binary) {
+        int rc = launch_pack_bits(s, bits, bpw, bsw, width, height, batch, vmax, st);
+        if (rc) return rc;
+        return launch_bitmorph(bits, bpw, bsw, d, width, height, batch, first_dil, nops, KX, KY, AX, AY, 0, vmax, st);
+    }
+    if (nops == 1) return launch_morph_generic(s, d, t1, width, height, batch, first_dil, KX, KY, AX, AY, st);
+    int rc = launch_morph_generic(s, t2, t1, width, height, batch, first_dil, KX, KY, AX, AY, st);
+    if (rc) return rc;
+    return launch_morph_generic(t2, d, t1, width, height, batch, !first_dil, KX, KY, AX, AY, st);
+}

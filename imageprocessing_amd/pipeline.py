@@ -1,0 +1,145 @@
+"""The fused raster front-end: what the reference's parsers run before contour logic.
+
+``front_end`` mirrors the caller wrappers ``load_image_from_file`` /
+``threshold_image`` / ``extract_lines`` of the reference
+(umlClassdiagram.py:12-30, umlSequencediagram.py:15-33,
+umlActivitydiagram.py:22-44, umlStateDiagram.py:12-30) followed by the
+line-detection prefix ``cvtColor -> [GaussianBlur] -> Canny -> HoughLines``
+(lineDetection.py:6-9, "New Version/comparison.py":30), with the same defaults
+(``vert_len = horiz_len = 15``, ``iterations = 2``).  The batched form runs the
+whole batch through one C call (`ipa_front_end_u8`): per-image Python overhead
+would otherwise dominate.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _native, cv2api
+from ._device import DevImage, check, error, stream_ptr, upload, workspace
+
+
+@dataclasses.dataclass
+class FrontEndResult:
+    gray: object
+    thresh: object
+    vlines: object
+    hlines: object
+    edges: object
+    accum: Optional[object] = None         # int32[batch, numangle+2, numrho+2] (device) when requested
+    lines: Optional[List[object]] = None   # per image: float32[N,1,2] or None
+
+
+class FrontEnd:
+    """Pre-planned front-end for a fixed (batch, height, width): owns the five output
+    planes, the Hough accumulators and the workspace, so that ``run`` allocates nothing."""
+
+    def __init__(self, batch: int, height: int, width: int, *, thresh_val: int = 128, vert_len: int = 15,
+                 horiz_len: int = 15, iterations: int = 2, canny=(50, 150), blur: bool = False, hough: bool = True,
+                 max_points: int = 0):
+        L = _native.lib()
+        self.batch, self.height, self.width = int(batch), int(height), int(width)
+        self.thresh_val, self.vert_len, self.horiz_len = int(thresh_val), int(vert_len), int(horiz_len)
+        self.iterations, self.canny, self.blur, self.hough = int(iterations), canny, bool(blur), bool(hough)
+        if self.vert_len < 1 or self.horiz_len < 1 or self.iterations < 1:
+            raise error("front_end: vert_len, horiz_len and iterations must be >= 1")
+        if max_points <= 0:
+            # edge maps of diagrams are sparse: keep room for 1/4 of the pixels, retry on overflow
+            max_points = max(1024, (self.height * self.width) // 4)
+        self.max_points = int(min(max_points, self.height * self.width)) if self.height * self.width else 0
+        self.planes = DevImage.empty(5 * max(self.batch, 1), self.height, self.width, 1)
+        self.na, self.nr = cv2api.hough_dims(self.width, self.height, 1.0, np.pi / 180)
+        dev = self.planes.t.device
+        if self.hough:
+            self.accum = torch.empty((max(self.batch, 1), self.na + 2, self.nr + 2), dtype=torch.int32, device=dev)
+            self.point_counts = torch.zeros(max(self.batch, 1), dtype=torch.int32, device=dev)
+        else:
+            self.accum = None
+            self.point_counts = None
+        self._alloc_ws()
+
+    def _alloc_ws(self):
+        L = _native.lib()
+        self.ws = workspace(L.ipa_front_end_workspace_bytes(self.width, self.height, self.batch,
+                                                            self.max_points if self.hough else 1))
+
+    def plane(self, k: int) -> DevImage:
+        """k: 0 gray, 1 thresh, 2 vlines, 3 hlines, 4 edges."""
+        b = max(self.batch, 1)
+        return DevImage(self.planes.t[k * b : (k + 1) * b], self.batch, self.height, self.width, 1)
+
+    def enqueue(self, bgr: DevImage) -> None:
+        """One pass over a device-resident batch.  Synchronises the stream while the Canny
+        hysteresis converges; Hough point-list overflow is checked by ``run``."""
+        L = _native.lib()
+        if (bgr.batch, bgr.height, bgr.width, bgr.channels) != (self.batch, self.height, self.width, 3):
+            raise error("front_end: input batch does not match the planned shape")
+        p = [self.plane(k) for k in range(5)]
+        check(L.ipa_front_end_u8(
+            bgr.ptr, bgr.pitch, bgr.stride, p[0].ptr, p[1].ptr, p[2].ptr, p[3].ptr, p[4].ptr, p[0].pitch, p[0].stride,
+            self.accum.data_ptr() if self.hough else None, self.accum.stride(0) if self.hough else 0,
+            self.max_points, self.point_counts.data_ptr() if self.hough else None,
+            self.width, self.height, self.batch, self.thresh_val, self.vert_len, self.horiz_len, self.iterations,
+            float(self.canny[0]), float(self.canny[1]), 1 if self.blur else 0,
+            self.ws.data_ptr(), self.ws.numel(), stream_ptr()))
+
+    def run(self, bgr: DevImage) -> None:
+        """``enqueue`` plus the overflow check of the Hough point lists (re-plans and re-runs
+        once with full-size lists if an image had more edge pixels than planned for)."""
+        self.enqueue(bgr)
+        if self.hough and self.batch:
+            most = int(self.point_counts[: self.batch].max().item())
+            if most > self.max_points:
+                self.max_points = self.height * self.width
+                self._alloc_ws()
+                self.enqueue(bgr)
+
+    def lines(self, threshold: int):
+        """Per-image cv2.HoughLines output from the accumulators of the last run."""
+        out = []
+        for b in range(self.batch):
+            keys = cv2api.hough_peaks(self.accum[b], int(threshold))
+            out.append(cv2api.lines_from_keys(keys, self.nr, 1.0, np.pi / 180) if keys.size else None)
+        return out
+
+
+def _result(fe: FrontEnd, like, squeeze: bool, hough_threshold) -> FrontEndResult:
+    to = (lambda d: d.to_tensor(squeeze)) if isinstance(like, torch.Tensor) else (lambda d: d.to_numpy(squeeze))
+    planes = [to(fe.plane(k)) for k in range(5)]
+    acc = None
+    if fe.hough:
+        acc = fe.accum[0] if squeeze else fe.accum[: fe.batch]
+    lines = fe.lines(hough_threshold) if (fe.hough and hough_threshold is not None) else None
+    if lines is not None and squeeze:
+        lines = lines[0]
+    return FrontEndResult(*planes, accum=acc, lines=lines)
+
+
+def front_end(img, thresh_val=128, vert_len=15, horiz_len=15, iterations=2, canny=(50, 150), blur=False,
+              hough_threshold=None, hough=True) -> FrontEndResult:
+    """Full front-end of ONE BGR image (numpy uint8[H,W,3] or ROCm tensor)."""
+    s = upload(img, 3)
+    fe = FrontEnd(1, s.height, s.width, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
+                  iterations=iterations, canny=canny, blur=blur, hough=hough)
+    fe.run(s)
+    return _result(fe, img, True, hough_threshold)
+
+
+def front_end_batch(images, thresh_val=128, vert_len=15, horiz_len=15, iterations=2, canny=(50, 150), blur=False,
+                    hough_threshold=None, hough=True) -> FrontEndResult:
+    """Full front-end of a batch uint8[N,H,W,3] in one device call."""
+    s = upload(images, 3, batched=True)
+    fe = FrontEnd(s.batch, s.height, s.width, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
+                  iterations=iterations, canny=canny, blur=blur, hough=hough)
+    fe.run(s)
+    return _result(fe, images, False, hough_threshold)
+
+
+def edges_and_lines(img, lo=50, hi=150, hough_threshold=100, blur=False):
+    """The prefix of lineDetection.py:6-9 with the standard accumulator instead of HoughLinesP:
+    gray -> [GaussianBlur 5x5] -> Canny(lo, hi) -> HoughLines(edges, 1, pi/180, hough_threshold)."""
+    r = front_end(img, canny=(lo, hi), blur=blur, hough_threshold=hough_threshold)
+    return r.gray, r.edges, r.lines

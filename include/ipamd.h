@@ -1,0 +1,245 @@
+/*
+ * ipamd.h -- C ABI of libipamd_hip.so, the MI355X (gfx950) raster front-end.
+ *
+ * The reference (jaculangithub/ImageProcessing) has no FFI layer of its own:
+ * its diagram parsers call `cv2.*` free functions on numpy arrays.  Each entry
+ * point below is what a binding for one of those cv2 calls would bind; the
+ * comment on each names the cv2 call and the reference call sites it replaces.
+ * The Python package `imageprocessing_amd` binds them with ctypes and presents
+ * the cv2 names on top.
+ *
+ * Conventions (all entry points):
+ *   - Every image pointer is a DEVICE pointer (HIP) to pixel (0,0) of image 0
+ *     of a batch; `*_pitch` is the byte distance between rows, `*_stride` the
+ *     byte distance between consecutive images of the batch.
+ *   - Pointers must be 16-byte aligned; pitches and strides multiples of 16
+ *     (ipa_pitch_for() returns a suitable pitch).  Bytes of a destination row
+ *     between `width` and the pitch may be overwritten.
+ *   - Planes are 8-bit unsigned, one channel, unless "bgr"/"c3" (3 interleaved
+ *     channels, B,G,R order).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     enqueue work and return without synchronising unless stated otherwise.
+ *   - `ws`/`ws_bytes` is caller-owned device scratch of at least the size the
+ *     matching ipa_*_workspace_bytes() query returns; the library allocates no
+ *     device memory.  Scratch contents are undefined after the call.
+ *   - Return value 0 = success, negative = IPA_ERR_*; ipa_last_error() gives a
+ *     thread-local message.
+ *   - Inputs are never modified; src and dst must not overlap unless stated.
+ */
+#ifndef IPAMD_H
+#define IPAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPA_OK 0
+#define IPA_ERR_ARG (-1)      /* bad size / parameter (cv2 would raise cv2.error) */
+#define IPA_ERR_ALIGN (-2)    /* pointer or pitch not 16-byte aligned */
+#define IPA_ERR_WORKSPACE (-3)/* workspace too small */
+#define IPA_ERR_HIP (-4)      /* a HIP runtime call failed */
+#define IPA_ERR_OVERFLOW (-5) /* a bounded output list was too small */
+
+/* cv2 constants accepted by the entry points */
+#define IPA_THRESH_BINARY 0
+#define IPA_THRESH_BINARY_INV 1
+#define IPA_MORPH_ERODE 0
+#define IPA_MORPH_DILATE 1
+#define IPA_MORPH_OPEN 2
+#define IPA_MORPH_CLOSE 3
+#define IPA_BORDER_CONSTANT 0
+#define IPA_BORDER_REPLICATE 1
+#define IPA_BORDER_REFLECT 2
+#define IPA_BORDER_REFLECT_101 4
+#define IPA_ADAPTIVE_THRESH_MEAN_C 0
+#define IPA_ADAPTIVE_THRESH_GAUSSIAN_C 1
+
+int ipa_version(void);
+const char* ipa_last_error(void);
+/* Smallest multiple of 256 that is >= row_bytes: the pitch the library prefers. */
+size_t ipa_pitch_for(size_t row_bytes);
+
+/* ---- colour conversion ------------------------------------------------- */
+
+/* cv2.cvtColor(img, cv2.COLOR_BGR2GRAY): umlClassdiagram.py:14,1121;
+ * umlSequencediagram.py:17,605; umlActivitydiagram.py:26,375,425;
+ * umlStateDiagram.py:14,360; lineDetection.py:6; shapeDetection.py:7. */
+int ipa_bgr2gray_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
+                    uint8_t* gray, size_t gray_pitch, size_t gray_stride,
+                    int width, int height, int batch, void* stream);
+
+/* cv2.cvtColor(gray, cv2.COLOR_GRAY2BGR): umlClassdiagram.py:1103. */
+int ipa_gray2bgr_u8(const uint8_t* gray, size_t gray_pitch, size_t gray_stride,
+                    uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
+                    int width, int height, int batch, void* stream);
+
+/* cv2.cvtColor(img, cv2.COLOR_RGB2BGR / COLOR_BGR2RGB):
+ * NewVersion2/text_detectionv2.py:17. */
+int ipa_swap_rb_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                   uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                   int width, int height, int batch, void* stream);
+
+/* cv2.bitwise_not: NewVersion2/text_detectionv2.py:22.  row_bytes = width*channels. */
+int ipa_bitwise_not_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                       uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                       int row_bytes, int height, int batch, void* stream);
+
+/* cv2.bitwise_or: "New Version/textDetection copy.py":94. */
+int ipa_bitwise_or_u8(const uint8_t* a, size_t a_pitch, size_t a_stride,
+                      const uint8_t* b, size_t b_pitch, size_t b_stride,
+                      uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                      int row_bytes, int height, int batch, void* stream);
+
+/* ---- thresholds -------------------------------------------------------- */
+
+/* cv2.threshold(gray, thresh, maxval, THRESH_BINARY | THRESH_BINARY_INV):
+ * umlClassdiagram.py:19; umlSequencediagram.py:22; umlActivitydiagram.py:34;
+ * umlStateDiagram.py:19; shapeDetection.py:10; testing.py:50;
+ * "New Version/imageToBlackandWhite.py":12.  The value cv2 returns is
+ * floor(thresh). */
+int ipa_threshold_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                     uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                     int width, int height, int batch,
+                     double thresh, double maxval, int type, void* stream);
+
+/* 256-bin histogram per image (uint32[batch][256], zeroed by the call); the
+ * first half of cv2.threshold(..., THRESH_OTSU):
+ * "New Version/textDetection.py":23. */
+int ipa_histogram_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                     int width, int height, int batch, uint32_t* hist, void* stream);
+
+/* cv2.threshold(img, _, maxval, type | THRESH_OTSU): histogram, Otsu scan in
+ * double precision and the threshold itself, all on the device.
+ * `hist` = uint32[batch][256] scratch/output, `otsu` = int32[batch] output
+ * (the value cv2 returns as retval). */
+int ipa_threshold_otsu_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                          uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                          int width, int height, int batch,
+                          double maxval, int type, uint32_t* hist, int32_t* otsu, void* stream);
+
+/* cv2.adaptiveThreshold(src, maxValue, method, type, blockSize, C):
+ * NewVersion2/img2UML.py:29; newVersion3/detect_arrow.py:19;
+ * "Version4 with Chatgpt/textDetection.py":15. */
+size_t ipa_adaptive_threshold_workspace_bytes(int width, int height, int batch);
+int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                              uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                              int width, int height, int batch,
+                              double max_value, int method, int type, int block_size, double c,
+                              void* ws, size_t ws_bytes, void* stream);
+
+/* ---- smoothing --------------------------------------------------------- */
+
+/* cv2.GaussianBlur(gray, (kw,kh), sigmaX, sigmaY=0, borderType):
+ * NewVersion2/img2UML.py:26; newVersion3/detect_arrow.py:16;
+ * newVersion3/detectHorizontalVerticalLines.py:58;
+ * "Version4 with Chatgpt/contour_detection.py":13; "images/with API/withAPI.py":50;
+ * "New Version/detectArrow.py":7.  8-bit fixed-point arithmetic as OpenCV's. */
+size_t ipa_gaussian_blur_workspace_bytes(int width, int height, int batch);
+int ipa_gaussian_blur_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                         uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                         int width, int height, int batch,
+                         int kw, int kh, double sigma_x, double sigma_y, int border,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- morphology -------------------------------------------------------- */
+
+/* cv2.erode / cv2.dilate / cv2.morphologyEx(src, op, kernel, iterations) with an
+ * all-ones kw x kh kernel (cv2.getStructuringElement(MORPH_RECT, (kw,kh)) or
+ * np.ones): umlClassdiagram.py:24-28; umlSequencediagram.py:27-31;
+ * umlActivitydiagram.py:38-42; umlStateDiagram.py:24-28;
+ * NewVersion2/img2UML.py:34-35; newVersion3/detect_arrow.py:24,28,39;
+ * "New Version/detectArrow.py":10-11; NewVersion2/detectArrowv2.py:23-24.
+ * anchor (-1,-1) = kernel centre.  `assume_binary` != 0 promises that every
+ * pixel is 0 or one common non-zero value and selects the bit-plane kernels;
+ * 0 selects the general 8-bit kernels.  Results are identical when the promise
+ * holds. */
+size_t ipa_morph_workspace_bytes(int width, int height, int batch);
+int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                 uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                 int width, int height, int batch,
+                 int op, int kw, int kh, int anchor_x, int anchor_y, int iterations,
+                 int assume_binary, void* ws, size_t ws_bytes, void* stream);
+
+/* Device-side test used before choosing `assume_binary`: flags[b] (int32[batch])
+ * becomes the common non-zero value of image b (0 for an all-zero image) or -1
+ * when the image holds two different non-zero values. */
+int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                        int width, int height, int batch, int32_t* flags, void* stream);
+
+/* ---- Canny ------------------------------------------------------------- */
+
+/* cv2.Canny(gray, t1, t2, apertureSize=3, L2gradient=False): lineDetection.py:9;
+ * "New Version/comparison.py":13; "Version4 with Chatgpt/contour_detection.py":61;
+ * newVersion3/detectHorizontalVerticalLines.py:61; "New Version/detectArrow.py":8.
+ * Hysteresis iterates until no tile changes; this call synchronises `stream`
+ * (once per convergence check). */
+size_t ipa_canny_workspace_bytes(int width, int height, int batch);
+int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                 uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                 int width, int height, int batch,
+                 double threshold1, double threshold2,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---- standard Hough transform ------------------------------------------ */
+
+/* Accumulator geometry of cv2.HoughLines(img, rho, theta, threshold)
+ * ("New Version/comparison.py":20,30): numangle rows of numrho bins, stored with
+ * a one-bin border as int32[(numangle+2)*(numrho+2)]. */
+int ipa_hough_dims(int width, int height, double rho, double theta, int* numangle, int* numrho);
+
+/* Vote accumulator for every non-zero pixel.  `accum` = int32 device array,
+ * image b at accum + b*accum_stride (elements); fully written by the call.
+ * `max_points` bounds the per-image list of non-zero pixels kept in scratch
+ * (0 = width*height); `point_counts` (int32[batch], device) receives the true
+ * number of non-zero pixels -- if any exceeds max_points the accumulator of
+ * that image is incomplete and the caller must retry with a larger bound. */
+size_t ipa_hough_workspace_bytes(int width, int height, int batch, int max_points);
+int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                       int width, int height, int batch, double rho, double theta,
+                       int32_t* accum, size_t accum_stride, int max_points, int32_t* point_counts,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* Local maxima of the accumulator above `threshold` (the findLocalMaximums step
+ * of cv2.HoughLines).  For image b, keys + b*capacity receives up to `capacity`
+ * 64-bit keys (votes << 32 | (0xFFFFFFFF - accumulator index)), in no particular
+ * order; sorting them in DESCENDING order yields cv2's line order.
+ * peak_counts[b] receives the number found (may exceed capacity: then only the
+ * first `capacity` were kept and the caller retries). */
+int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle, int numrho, int batch,
+                        int threshold, uint64_t* keys, int capacity, int32_t* peak_counts, void* stream);
+
+/* ---- fused front-end ---------------------------------------------------- */
+
+/* One pass of the whole raster front-end over a batch of BGR images: the
+ * composition the reference's parsers run before their contour logic --
+ * load_image_from_file / threshold_image / extract_lines
+ * (umlClassdiagram.py:12-30, umlSequencediagram.py:15-33,
+ * umlActivitydiagram.py:22-44, umlStateDiagram.py:12-30) plus the line-detection
+ * prefix cvtColor -> [GaussianBlur 5x5] -> Canny -> HoughLines
+ * (lineDetection.py:6-9, newVersion3/detectHorizontalVerticalLines.py:55-64,
+ * "New Version/comparison.py":30):
+ *   gray   = cvtColor(bgr, BGR2GRAY)
+ *   thresh = threshold(gray, thresh_val, 255, THRESH_BINARY_INV)
+ *   vlines = morphologyEx(thresh, OPEN, rect(1, vert_len), iterations)
+ *   hlines = morphologyEx(thresh, OPEN, rect(horiz_len, 1), iterations)
+ *   edges  = Canny(blur5x5 ? GaussianBlur(gray,(5,5),0) : gray, canny_lo, canny_hi)
+ *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL)
+ * The five output planes share one pitch/stride.  Synchronises `stream` as
+ * ipa_canny_u8 does. */
+size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points);
+int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
+                     uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,
+                     size_t plane_pitch, size_t plane_stride,
+                     int32_t* accum, size_t accum_stride, int max_points, int32_t* point_counts,
+                     int width, int height, int batch,
+                     int thresh_val, int vert_len, int horiz_len, int iterations,
+                     double canny_lo, double canny_hi, int blur5x5,
+                     void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPAMD_H */

@@ -1,0 +1,392 @@
+"""GPU parity: the HIP kernels (through the C ABI, via the cv2-style module) against
+the CPU oracle on the same inputs.  Bit-exact for every op except GaussianBlur with an
+explicit sigma, whose stated tolerance is +-1 LSB (exactness is still asserted against
+our own oracle; the tolerance is the bar against cv2).
+
+Expected values come from ``oracle/`` ("restatement"), from the cv2-written artefact pair
+in ``tests/golden/gray_kat.npz`` ("cv2-artefact") or are derived by hand ("analytic").
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontref as fr
+from tests.conftest import uml_like
+
+pytestmark = pytest.mark.gpu
+
+cv2 = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _mod():
+    global cv2
+    import imageprocessing_amd as m
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    cv2 = m
+    yield
+
+
+def rand_gray(seed, h, w):
+    return np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+
+
+def smooth_gray(seed, h, w):
+    from scipy import ndimage
+
+    a = np.random.default_rng(seed).integers(0, 256, (h, w)).astype(np.float32)
+    return ndimage.gaussian_filter(a, 2.0).astype(np.uint8)
+
+
+SIZES = [(1, 1), (1, 37), (37, 1), (2, 2), (16, 16), (33, 47), (127, 129), (200, 454), (381, 454), (97, 1031)]
+
+
+# ------------------------------------------------------------------ colour / bytes
+def test_gray_kat_cv2_artefact(gray_kat):
+    assert np.array_equal(cv2.cvtColor(gray_kat["bgr"], cv2.COLOR_BGR2GRAY), gray_kat["gray"])
+    cols = gray_kat["colours_bgr"][None]
+    assert np.array_equal(cv2.cvtColor(cols, cv2.COLOR_BGR2GRAY)[0], gray_kat["colours_gray"])
+    assert np.array_equal(cv2.bitwise_not(gray_kat["bgr"]), gray_kat["inverted_bgr"])
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_cvtcolor_sizes(h, w):
+    bgr = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    g = cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY)
+    assert g.shape == (h, w) and g.dtype == np.uint8
+    assert np.array_equal(g, fr.bgr2gray(bgr))
+    assert np.array_equal(cv2.cvtColor(g, cv2.COLOR_GRAY2BGR), fr.gray2bgr(g))
+    assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2RGB), bgr[..., ::-1])
+    assert np.array_equal(cv2.bitwise_not(g), 255 - g)
+    g2 = rand_gray(5, h, w)
+    assert np.array_equal(cv2.bitwise_or(g, g2), g | g2)
+
+
+def test_cvtcolor_all_colours_exhaustive_slice():
+    # every (B, G, R) with B, R stepping 5 and G full range: 52*256*52 colours
+    b, g, r = np.meshgrid(np.arange(0, 256, 5), np.arange(256), np.arange(0, 256, 5), indexing="ij")
+    bgr = np.stack([b, g, r], -1).astype(np.uint8).reshape(52 * 256, 52, 3)
+    assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), fr.bgr2gray(bgr))
+
+
+def test_device_tensor_in_out():
+    bgr = np.random.default_rng(3).integers(0, 256, (64, 80, 3), dtype=np.uint8)
+    t = torch.from_numpy(bgr).cuda()
+    g = cv2.cvtColor(t, cv2.COLOR_BGR2GRAY)
+    assert isinstance(g, torch.Tensor) and g.is_cuda and g.shape == (64, 80)
+    assert np.array_equal(g.cpu().numpy(), fr.bgr2gray(bgr))
+    t2 = torch.from_numpy(bgr[:, :77].copy()).cuda()  # row bytes not a multiple of 16
+    assert np.array_equal(cv2.cvtColor(t2, cv2.COLOR_BGR2GRAY).cpu().numpy(), fr.bgr2gray(bgr[:, :77]))
+
+
+def test_errors_like_cv2():
+    with pytest.raises(cv2.error):
+        cv2.cvtColor(np.zeros((4, 4), np.uint8), cv2.COLOR_BGR2GRAY)
+    with pytest.raises(cv2.error):
+        cv2.Canny(np.zeros((4, 4), np.float32), 50, 150)
+    with pytest.raises(cv2.error):
+        cv2.GaussianBlur(np.zeros((4, 4), np.uint8), (4, 4), 0)
+    with pytest.raises(cv2.error):
+        cv2.adaptiveThreshold(np.zeros((4, 4), np.uint8), 255, cv2.ADAPTIVE_THRESH_GAUSSIAN_C, cv2.THRESH_BINARY, 10, 2)
+    with pytest.raises(cv2.error):
+        cv2.adaptiveThreshold(np.zeros((4, 4), np.uint8), 255, cv2.ADAPTIVE_THRESH_GAUSSIAN_C, cv2.THRESH_BINARY, 1, 2)
+    assert isinstance(cv2.error("x"), Exception)
+
+
+# ------------------------------------------------------------------ thresholds
+@pytest.mark.parametrize("t", [100, 127, 128, 150, 200, 240, 0, 255, -5, 300, 127.9])
+@pytest.mark.parametrize("typ", [0, 1])
+def test_threshold(t, typ):
+    g = rand_gray(11, 61, 203)
+    r, d = cv2.threshold(g, t, 255, typ)
+    r0, d0 = fr.threshold(g, t, 255, typ)
+    assert r == r0 and np.array_equal(d, d0)
+
+
+def test_threshold_maxval():
+    g = rand_gray(12, 40, 77)
+    for mv in (0, 1, 200.4, 200.5, 300):
+        assert np.array_equal(cv2.threshold(g, 99, mv, 0)[1], fr.threshold(g, 99, mv, 0)[1])
+
+
+@pytest.mark.parametrize("h,w", [(33, 47), (381, 454), (97, 1031), (1, 1)])
+def test_otsu(h, w, cd_bgr):
+    imgs = [rand_gray(1, h, w), smooth_gray(2, h, w), np.full((h, w), 255, np.uint8)]
+    if (h, w) == (381, 454):
+        imgs.append(fr.bgr2gray(cd_bgr))
+    for g in imgs:
+        for typ in (8, 9):
+            r, d = cv2.threshold(g, 0, 255, typ)
+            r0, d0 = fr.threshold(g, 0, 255, typ)
+            assert r == r0, (r, r0)
+            assert np.array_equal(d, d0)
+
+
+def test_histogram_white_page():
+    # 97 % one value: exercises the wave-uniform fast path and the mixed path together
+    img = uml_like(77, 300, 1040)
+    g = fr.bgr2gray(img)
+    r, d = cv2.threshold(g, 0, 255, cv2.THRESH_BINARY + cv2.THRESH_OTSU)
+    r0, d0 = fr.threshold(g, 0, 255, 8)
+    assert r == r0 and np.array_equal(d, d0)
+
+
+@pytest.mark.parametrize("block", [3, 11, 31])
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("typ", [0, 1])
+def test_adaptive_threshold(block, method, typ):
+    for g in (rand_gray(4, 67, 131), smooth_gray(5, 90, 77), fr.bgr2gray(uml_like(6, 120, 333))):
+        a = cv2.adaptiveThreshold(g, 255, method, typ, block, 2)
+        b = fr.adaptive_threshold(g, 255, method, typ, block, 2)
+        assert np.array_equal(a, b), (block, method, typ, int((a != b).sum()))
+    g = rand_gray(9, 20, 20)
+    assert np.array_equal(cv2.adaptiveThreshold(g, 200, 1, 0, 5, -3.5), fr.adaptive_threshold(g, 200, 1, 0, 5, -3.5))
+
+
+# ------------------------------------------------------------------ blur
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (5, 5), (33, 47), (127, 129), (381, 454)])
+def test_gaussian_5x5_sigma0_exact(h, w):
+    for g in (rand_gray(h + w, h, w), smooth_gray(w, h, w)):
+        assert np.array_equal(cv2.GaussianBlur(g, (5, 5), 0), fr.gaussian_blur(g, (5, 5), 0))
+
+
+@pytest.mark.parametrize("ks,sx,sy", [((3, 3), 0, 0), ((5, 5), 1, 0), ((7, 7), 0, 0), ((9, 9), 0, 0), ((11, 11), 2.0, 0),
+                                      ((5, 3), 1.5, 0.7), ((0, 0), 1.2, 0), ((31, 31), 5, 0)])
+def test_gaussian_general(ks, sx, sy):
+    g = rand_gray(21, 70, 101)
+    a = cv2.GaussianBlur(g, ks, sx, sigmaY=sy)
+    b = fr.gaussian_blur(g, ks, sx, sy)
+    assert np.array_equal(a, b)  # same quantised taps => bit exact vs the oracle; +-1 LSB is the bar vs cv2
+
+
+@pytest.mark.parametrize("border", [0, 1, 2, 4])
+def test_gaussian_borders(border):
+    g = rand_gray(22, 19, 23)
+    assert np.array_equal(cv2.GaussianBlur(g, (7, 7), 1.3, borderType=border), fr.gaussian_blur(g, (7, 7), 1.3, 0, border))
+
+
+# ------------------------------------------------------------------ morphology
+MORPH_CASES = [((3, 3), 1), ((3, 3), 2), ((15, 1), 2), ((1, 15), 2), ((2, 2), 1), ((4, 3), 2), ((1, 1), 3), ((5, 7), 0),
+               ((30, 1), 1), ((1, 30), 1), ((101, 1), 2), ((1, 101), 2), ((33, 1), 1), ((1, 64), 1)]
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+@pytest.mark.parametrize("ks,it", MORPH_CASES)
+def test_morph_binary_images(op, ks, it):
+    # two-valued inputs -> bit-plane kernels
+    rng = np.random.default_rng(ks[0] * 100 + ks[1] + it)
+    imgs = [
+        (rng.random((64, 131)) < 0.6).astype(np.uint8) * 255,
+        fr.threshold(fr.bgr2gray(uml_like(31, 260, 600)), 128, 255, 1)[1],
+        (rng.random((300, 70)) < 0.9).astype(np.uint8) * 200,  # a non-255 foreground value
+        np.zeros((9, 9), np.uint8),
+        np.full((40, 33), 255, np.uint8),
+    ]
+    k = np.ones((ks[1], ks[0]), np.uint8)
+    for img in imgs:
+        a = cv2.morphologyEx(img, op, k, iterations=it)
+        b = fr.morphology_ex(img, op, ks, it)
+        assert np.array_equal(a, b), (op, ks, it, img.shape, int((a != b).sum()))
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+@pytest.mark.parametrize("ks,it", MORPH_CASES[:9] + [((101, 1), 1), ((1, 101), 1)])
+def test_morph_gray_images(op, ks, it):
+    imgs = [rand_gray(8, 37, 53), smooth_gray(9, 90, 1100), rand_gray(10, 300, 5)]
+    k = np.ones((ks[1], ks[0]), np.uint8)
+    for img in imgs:
+        a = cv2.morphologyEx(img, op, k, iterations=it)
+        b = fr.morphology_ex(img, op, ks, it)
+        assert np.array_equal(a, b), (op, ks, it, img.shape, int((a != b).sum()))
+
+
+def test_erode_dilate_api_and_anchor():
+    img = (np.random.default_rng(2).random((50, 60)) < 0.5).astype(np.uint8) * 255
+    g = rand_gray(3, 50, 60)
+    for src in (img, g):
+        assert np.array_equal(cv2.dilate(src, np.ones((2, 2), np.uint8)), fr.morphology_ex(src, 1, (2, 2)))
+        assert np.array_equal(cv2.erode(src, np.ones((3, 3)), iterations=2), fr.morphology_ex(src, 0, (3, 3), 2))
+        assert np.array_equal(cv2.dilate(src, None), fr.morphology_ex(src, 1, (3, 3)))
+        assert np.array_equal(cv2.erode(src, np.ones((5, 4), np.uint8), anchor=(0, 3)),
+                              fr.morphology_ex(src, 0, (4, 5), 1, (0, 3)))
+    k = cv2.getStructuringElement(cv2.MORPH_RECT, (1, 15))
+    assert k.shape == (15, 1) and k.dtype == np.uint8 and k.all()
+
+
+def test_open_keeps_runs_of_29_analytic():
+    img = np.zeros((5, 200), np.uint8)
+    img[1, 10:38] = 255
+    img[3, 10:39] = 255
+    out = cv2.morphologyEx(img, cv2.MORPH_OPEN, cv2.getStructuringElement(cv2.MORPH_RECT, (15, 1)), iterations=2)
+    assert out[1].sum() == 0 and np.array_equal(out[3], img[3])
+
+
+# ------------------------------------------------------------------ Canny
+@pytest.mark.parametrize("h,w", SIZES + [(64, 256), (33, 128), (32, 129)])
+def test_canny_random_and_smooth(h, w):
+    for g in (rand_gray(h * 7 + w, h, w), smooth_gray(h + w * 3, h, w)):
+        for lo, hi in ((50, 150), (50, 50), (200, 100), (10, 400)):
+            a = cv2.Canny(g, lo, hi)
+            b = fr.canny(g, lo, hi)
+            assert np.array_equal(a, b), (h, w, lo, hi, int((a != b).sum()))
+
+
+def test_canny_reference_images(cd_bgr, login_bgr):
+    for bgr in (cd_bgr, login_bgr):
+        g = fr.bgr2gray(bgr)
+        assert np.array_equal(cv2.Canny(g, 50, 150, apertureSize=3), fr.canny(g, 50, 150))
+        blur = fr.gaussian_blur(g, (5, 5), 0)
+        assert np.array_equal(cv2.Canny(blur, 50, 150), fr.canny(blur, 50, 150))
+
+
+def _weak_staircase(h, w):
+    """A low-contrast staircase boundary (magnitude 80: weak only) spanning the whole width."""
+    g = np.full((h, w), 200, np.uint8)
+    y, x, step = 20, 0, 0
+    while x < w:
+        x1 = min(x + 97, w)
+        g[y:, x:x1] = 180
+        x = x1
+        y += 9 if step % 2 == 0 else -5
+        step += 1
+    return g
+
+
+def test_canny_long_weak_chains_cross_many_tiles():
+    # hysteresis must walk a weak-only chain from one strong seed across a dozen tiles
+    g = _weak_staircase(200, 1500)
+    assert cv2.Canny(g, 50, 150).sum() == 0 == fr.canny(g, 50, 150).sum()  # no seed -> nothing survives
+    g[18:24, 0:4] = 0  # strong seed at the left end
+    a = cv2.Canny(g, 50, 150)
+    b = fr.canny(g, 50, 150)
+    assert b.sum() > 255 * 1500  # the chain really spans the image
+    assert np.array_equal(a, b)
+    # and right-to-left / bottom-to-top through a transposed, flipped copy
+    g2 = np.ascontiguousarray(g[:, ::-1].T)
+    assert np.array_equal(cv2.Canny(g2, 50, 150), fr.canny(g2, 50, 150))
+
+
+def test_canny_noisy_whiteboard():
+    bgr = uml_like(9000, 500, 900, noise=6)
+    g = fr.bgr2gray(bgr)
+    assert np.array_equal(cv2.Canny(g, 50, 150), fr.canny(g, 50, 150))
+    assert np.array_equal(cv2.Canny(g, 20, 60), fr.canny(g, 20, 60))
+
+
+# ------------------------------------------------------------------ Hough
+def _acc(img, rho=1, theta=np.pi / 180):
+    return cv2.hough_accumulator(img, rho, theta).cpu().numpy()
+
+
+def test_hough_analytic():
+    img = np.zeros((40, 60), np.uint8)
+    img[7, 11] = 255
+    acc = _acc(img)
+    assert acc.shape == (182, 203) and acc.sum() == 180 and acc.max() == 1
+    assert acc[1, 11 + 100 + 1] == 1 and acc[91, 7 + 100 + 1] == 1
+    assert cv2.HoughLines(np.zeros((10, 10), np.uint8), 1, np.pi / 180, 2) is None
+    img[:] = 0
+    img[20, 5:55] = 255
+    lines = cv2.HoughLines(img, 1, np.pi / 180, 40)
+    assert lines.dtype == np.float32 and lines.shape[1:] == (1, 2)
+    assert lines[0, 0, 0] == 20.0 and lines[0, 0, 1] == np.float32(90) * np.float32(np.pi / 180)
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (33, 47), (127, 129), (381, 454), (97, 1031)])
+def test_hough_accumulator_counts(h, w):
+    rng = np.random.default_rng(h + w)
+    for dens in (0.02, 0.5, 1.0):
+        img = (rng.random((h, w)) < dens).astype(np.uint8) * 255
+        acc = _acc(img)
+        ref = fr.hough_accum(img, 1, np.pi / 180)
+        assert acc.shape == ref.shape
+        assert np.array_equal(acc, ref), (h, w, dens, int((acc != ref).sum()))
+
+
+def test_hough_other_resolutions():
+    img = (np.random.default_rng(5).random((90, 120)) < 0.05).astype(np.uint8) * 7  # any non-zero counts
+    for rho, theta in ((2, np.pi / 180), (1, np.pi / 90), (0.5, np.pi / 360), (3, np.pi / 45)):
+        assert np.array_equal(_acc(img, rho, theta), fr.hough_accum(img, rho, theta))
+        a, b = cv2.HoughLines(img, rho, theta, 6), fr.hough_lines(img, rho, theta, 6)
+        assert (a is None and b is None) or np.array_equal(a, b)
+
+
+def test_hough_lines_reference_images(cd_bgr, login_bgr):
+    # the calls of "New Version/comparison.py":20,30 (threshold 2) and a practical threshold
+    for bgr in (cd_bgr, login_bgr[:400, :600]):
+        g = fr.bgr2gray(bgr)
+        edges = fr.canny(g, 50, 150)
+        binary = fr.threshold(g, 127, 255, 1)[1]
+        for src in (edges, binary):
+            for thr in (2, 80):
+                a = cv2.HoughLines(src, 1, np.pi / 180, thr)
+                b = fr.hough_lines(src, 1, np.pi / 180, thr)
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ fused front-end
+def _check_front_end(res, bgr, t, vl, hl, it, lo, hi, blur):
+    g = fr.bgr2gray(bgr)
+    th = fr.threshold(g, t, 255, 1)[1]
+    assert np.array_equal(res.gray, g)
+    assert np.array_equal(res.thresh, th)
+    assert np.array_equal(res.vlines, fr.morphology_ex(th, 2, (1, vl), it))
+    assert np.array_equal(res.hlines, fr.morphology_ex(th, 2, (hl, 1), it))
+    src = fr.gaussian_blur(g, (5, 5), 0) if blur else g
+    e = fr.canny(src, lo, hi)
+    assert np.array_equal(res.edges, e)
+    assert np.array_equal(res.accum.cpu().numpy(), fr.hough_accum(e, 1, np.pi / 180))
+
+
+@pytest.mark.parametrize("t", [150, 128, 100])
+def test_front_end_reference_images(t, cd_bgr, login_bgr):
+    for bgr in (cd_bgr, login_bgr):
+        res = cv2.front_end(bgr, thresh_val=t)
+        _check_front_end(res, bgr, t, 15, 15, 2, 50, 150, False)
+
+
+def test_front_end_variants():
+    bgr = uml_like(1000, 270, 480)
+    _check_front_end(cv2.front_end(bgr, blur=True), bgr, 128, 15, 15, 2, 50, 150, True)
+    _check_front_end(cv2.front_end(bgr, vert_len=30, horiz_len=9, iterations=1), bgr, 128, 30, 9, 1, 50, 150, False)
+    r = cv2.front_end(bgr, hough_threshold=60)
+    e = fr.canny(fr.bgr2gray(bgr), 50, 150)
+    ref = fr.hough_lines(e, 1, np.pi / 180, 60)
+    assert (r.lines is None) == (ref is None)
+    if ref is not None:
+        assert np.array_equal(r.lines, ref)
+
+
+def test_front_end_batch_matches_single():
+    n, h, w = 5, 135, 241
+    batch = np.stack([uml_like(2000 + i, h, w, noise=(4 if i % 2 else 0)) for i in range(n)])
+    res = cv2.front_end_batch(batch)
+    assert res.gray.shape == (n, h, w)
+    for i in range(n):
+        single = cv2.FrontEndResult(res.gray[i], res.thresh[i], res.vlines[i], res.hlines[i], res.edges[i], res.accum[i])
+        _check_front_end(single, batch[i], 128, 15, 15, 2, 50, 150, False)
+
+
+def test_front_end_1080p_config1():
+    # BASELINE config 1: one 1920x1080 class-diagram raster, seed 1000, 12 boxes
+    bgr = uml_like(1000, 1080, 1920)
+    res = cv2.front_end(bgr)
+    _check_front_end(res, bgr, 128, 15, 15, 2, 50, 150, False)
+
+
+def test_front_end_point_list_overflow_retries():
+    # an image whose edge map is denser than the planned point list forces the re-plan path
+    g = np.zeros((64, 64), np.uint8)
+    g[::2, ::2] = 255
+    bgr = np.repeat(g[..., None], 3, axis=2)
+    from imageprocessing_amd import FrontEnd
+    from imageprocessing_amd._device import upload
+
+    fe = FrontEnd(1, 64, 64, max_points=16)
+    fe.run(upload(bgr, 3))
+    e = fr.canny(fr.bgr2gray(bgr), 50, 150)
+    assert np.count_nonzero(e) > 16
+    assert np.array_equal(fe.accum[0].cpu().numpy(), fr.hough_accum(e, 1, np.pi / 180))
