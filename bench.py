@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Headline benchmark: megapixels/second through the full raster front-end
+(BGR -> gray -> binary threshold -> vertical/horizontal line opening -> Canny ->
+Hough accumulator + peaks) on synthetic UML-like rasters.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size 4k|1080p|16k] [--no-cpu]
+
+N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``:
+one process per GPU, every rank runs the same per-GPU batch of its own images (weak
+scaling, per-image sharding, no data-path collective); the only communication is the
+barrier and the max-reduce of the elapsed time.
+
+A step = one pass of ``ipa_front_end_u8`` + ``ipa_hough_peaks_i32`` over a batch that is
+already resident in HBM.  The JSON line also carries the roofline of the dominant kernel
+(HIP-event timed inside the timed steps) and the CPU baseline (the C restatement in
+``oracle/`` on the host cores, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SIZES = {"1080p": (1080, 1920), "4k": (2160, 3840), "16k": (16384, 16384)}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def _gen_one(args):
+    from imageprocessing_amd.synth import synth_diagram
+
+    shm_name, idx, seed, h, w, kw = args
+    from multiprocessing import shared_memory
+
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        arr = np.ndarray((h, w, 3), dtype=np.uint8, buffer=shm.buf, offset=idx * h * w * 3)
+        arr[...] = synth_diagram(seed, h, w, **kw)
+    finally:
+        shm.close()
+    return idx
+
+
+class HostGenerator:
+    """Forked worker pool + one shared-memory chunk, created BEFORE the GPU is initialised
+    (workers never touch the GPU).  Falls back to in-process generation."""
+
+    def __init__(self, n, h, w, workers):
+        self.n, self.h, self.w = n, h, w
+        self.chunk = max(1, min(n, (1 << 30) // (h * w * 3)))
+        self.pool = None
+        self.shm = None
+        if workers > 1 and n > 1:
+            try:
+                import multiprocessing as mp
+                from multiprocessing import shared_memory
+
+                self.shm = shared_memory.SharedMemory(create=True, size=self.chunk * h * w * 3)
+                self.pool = mp.get_context("fork").Pool(workers)
+            except Exception:
+                self.close()
+
+    def chunks(self, seed0, kw):
+        from imageprocessing_amd.synth import synth_diagram
+
+        n, h, w = self.n, self.h, self.w
+        for c0 in range(0, n, self.chunk):
+            m = min(self.chunk, n - c0)
+            if self.pool is not None:
+                list(self.pool.imap_unordered(_gen_one, [(self.shm.name, i, seed0 + c0 + i, h, w, kw) for i in range(m)]))
+                host = np.ndarray((m, h, w * 3), dtype=np.uint8, buffer=self.shm.buf)
+            else:
+                host = np.stack([synth_diagram(seed0 + c0 + i, h, w, **kw) for i in range(m)]).reshape(m, h, w * 3)
+            yield c0, m, host
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.close()
+            self.pool.join()
+            self.pool = None
+        if self.shm is not None:
+            self.shm.close()
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
+            self.shm = None
+
+
+def generate_to_device(gen, seed0, kw):
+    """Synthetic diagrams -> pitched device batch, uploaded chunk by chunk."""
+    import torch
+    from imageprocessing_amd._device import DevImage
+
+    img = DevImage.empty(gen.n, gen.h, gen.w, 3)
+    try:
+        for c0, m, host in gen.chunks(seed0, kw):
+            img.t[c0 : c0 + m, : gen.h, : gen.w * 3].copy_(torch.from_numpy(host))
+            torch.cuda.synchronize()
+    finally:
+        gen.close()
+    return img
+
+
+def cpu_baseline(h, w, kw, seconds_target=12.0):
+    """The oracle's front-end (C restatement, OpenMP) on the host cores over a bounded sample."""
+    from imageprocessing_amd.synth import synth_diagram
+    from oracle import frontref as fr
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    fr.lib()
+    imgs = [synth_diagram(2000 + i, h, w, **kw) for i in range(2)]
+    fr.front_end(imgs[0])  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fr.front_end(imgs[n % len(imgs)])
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds_target or n >= 64:
+            break
+    mpix = n * h * w / 1e6 / el
+    return {"value": round(mpix, 2), "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "sample": f"{n} x {w}x{h} synthetic diagrams, full front-end incl. Hough accumulator, "
+                      f"oracle/frontref.c with OpenMP ({threads} threads), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 1024 for 4k, 1 otherwise)")
+    ap.add_argument("--size", default="4k", choices=list(SIZES))
+    ap.add_argument("--hough-threshold", type=int, default=200)
+    ap.add_argument("--blur", action="store_true", help="variant B: GaussianBlur 5x5 before Canny")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--check", type=int, default=2, help="images per rank verified against the oracle after the run")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with "
+                  f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}",
+                  file=sys.stderr)
+            sys.exit(2)
+    h, w = SIZES[args.size]
+    batch = args.batch or (1024 if args.size == "4k" else 1)
+    kw = {"noise": 6, "gradient": True} if args.size == "16k" else {}
+    line_len = 101 if args.size == "16k" else 15
+    seed0 = {"1080p": 1000, "4k": 2000, "16k": 9000}[args.size] + rank * batch
+
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    gen = HostGenerator(batch, h, w, workers)  # forks its workers before the GPU is touched
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import imageprocessing_amd as ipa
+    from imageprocessing_amd import _native
+
+    L = _native.lib()
+    dev = torch.device("cuda", local_rank)
+    t_gen = time.perf_counter()
+    bgr = generate_to_device(gen, seed0, kw)
+    t_gen = time.perf_counter() - t_gen
+
+    fe = ipa.FrontEnd(batch, h, w, thresh_val=128, vert_len=line_len, horiz_len=line_len, iterations=2,
+                      canny=(50, 150), blur=args.blur, hough=True)
+    cap = 4096
+    keys = torch.empty((batch, cap), dtype=torch.int64, device=dev)
+    peak_counts = torch.zeros(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        fe.enqueue(bgr)
+        rc = L.ipa_hough_peaks_i32(fe.accum.data_ptr(), fe.accum.stride(0), fe.na, fe.nr, batch, args.hough_threshold,
+                                   keys.data_ptr(), cap, peak_counts.data_ptr(), stream)
+        if rc:
+            raise RuntimeError(_native.last_error())
+
+    # first step also sizes the Hough point lists (re-plans on overflow)
+    fe.run(bgr)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.ipa_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.ipa_profile_enable(0)
+    nst = L.ipa_profile_stage_count()
+    ms = (C.c_double * nst)()
+    cnt = (C.c_int * nst)()
+    L.ipa_profile_collect(ms, cnt)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness spot check outside the timed region (oracle = checker only)
+    check_note = "skipped"
+    if args.check > 0:
+        from oracle import frontref as fr
+
+        bad = 0
+        ids = sorted(set(np.linspace(0, batch - 1, min(args.check, batch)).astype(int).tolist()))
+        for i in ids:
+            src = bgr.t[i, :h, : w * 3].cpu().numpy().reshape(h, w, 3)
+            ref = fr.front_end(src, 128, line_len, 2, 50, 150)
+            if args.blur:
+                g = fr.bgr2gray(src)
+                e = fr.canny(fr.gaussian_blur(g, (5, 5), 0), 50, 150)
+                ref = (ref[0], ref[1], ref[2], ref[3], e, fr.hough_accum(e, 1.0, np.pi / 180))
+            for k in range(5):
+                got = fe.plane(k).t[i, :h, :w].cpu().numpy()
+                bad += int(not np.array_equal(got, ref[k]))
+            bad += int(not np.array_equal(fe.accum[i].cpu().numpy(), ref[5]))
+        check_note = f"{len(ids)} images x 6 outputs bit-exact vs oracle" if bad == 0 else f"{bad} MISMATCHING outputs"
+        if bad:
+            print(f"bench.py: rank {rank}: parity check failed: {check_note}", file=sys.stderr)
+
+    if rank == 0:
+        npix = float(batch) * h * w
+        acc_bytes = 4.0 * (fe.na + 2) * (fe.nr + 2)
+        stage_names = [L.ipa_profile_stage_name(i).decode() for i in range(nst)]
+        # algorithmic bytes each stage has to move per image (conservative: never more than
+        # the per-op figures of the measurement plan)
+        alg = {
+            "gray_thresh_pack": 5.0 * h * w,          # BGR in (3) + gray out (1) + thresh out (1)
+            "open_vertical": 1.125 * h * w,           # 1 bit/px in + 1 B/px out
+            "open_horizontal": 1.125 * h * w,
+            "gaussian_blur": 2.0 * h * w,
+            "canny_nms": 2.0 * h * w,                 # gray in + edges out
+            "canny_hysteresis": 0.0,
+            "hough_compact": 1.0 * h * w,             # edges in (the point list is << 1 B/px)
+            "hough_vote": acc_bytes,                  # accumulator written once
+            "hough_peaks": acc_bytes,                 # accumulator read once
+        }
+        stages = {}
+        for i, nm in enumerate(stage_names):
+            if cnt[i]:
+                per = ms[i] / cnt[i]
+                stages[nm] = {"ms": round(per, 4), "GBps": round(alg[nm] * batch / (per * 1e-3) / 1e9, 1) if per > 0 else None}
+        dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None
+        roof = None
+        if dom:
+            a = alg[dom] * batch / (stages[dom]["ms"] * 1e-3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(f"{args.size}x{batch}", {}).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launch_ms": stages[dom]["ms"], "algorithmic_bytes_per_launch": alg[dom] * batch}
+        cpu = None
+        if not args.no_cpu:
+            try:
+                cpu = cpu_baseline(h, w, kw)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                cpu = {"error": str(e)}
+        value = npix * world * args.steps / elapsed / 1e6
+        whole = (8.0 * npix + acc_bytes * batch) * args.steps / elapsed / 1e9
+        out = {
+            "metric": "megapixels/sec through binarize+morph+Canny+Hough",
+            "value": round(value, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{batch} x {w}x{h} synthetic UML diagrams per GPU, full front-end "
+                                   f"(gray, threshold 128 INV, open 1x{line_len}/{line_len}x1 it=2, "
+                                   f"{'GaussianBlur 5x5, ' if args.blur else ''}Canny 50/150, Hough 1/pi/180 + peaks>"
+                                   f"{args.hough_threshold})",
+                       "images_per_gpu": batch, "width": w, "height": h, "sharding": "per-image, no collective"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "pipeline_algorithmic_GBps_per_gpu": round(whole, 1),
+            "pipeline_roofline_frac": round(whole / HBM_PEAK_GBS, 4),
+            "stages": stages,
+            "parity_check": check_note,
+            "gen_seconds": round(t_gen, 1),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

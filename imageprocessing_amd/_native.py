@@ -26,6 +26,10 @@ SIGNATURES = {
     "ipa_version": (_i, []),
     "ipa_last_error": (C.c_char_p, []),
     "ipa_pitch_for": (_sz, [_sz]),
+    "ipa_profile_enable": (_i, [_i]),
+    "ipa_profile_stage_count": (_i, []),
+    "ipa_profile_stage_name": (C.c_char_p, [_i]),
+    "ipa_profile_collect": (_i, [C.POINTER(_d), C.POINTER(_i)]),
     "ipa_bgr2gray_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _vp]),
     "ipa_gray2bgr_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _vp]),
     "ipa_swap_rb_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _vp]),

@@ -16,6 +16,81 @@ void ipa_set_error(const char* fmt, ...)
 }
 
 IPA_EXPORT int ipa_version(void) { return 100; }
+
+// ---- per-stage timing ---------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec {
+    int stage;
+    hipEvent_t a, b;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<ProfRec> g_prof_open;
+}  // namespace
+
+void prof_begin(int stage, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.stage = stage;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, st);
+    g_prof_open.push_back(r);
+}
+
+void prof_end(int stage, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = g_prof_open.size(); i-- > 0;)
+        if (g_prof_open[i].stage == stage) {
+            hipEventRecord(g_prof_open[i].b, st);
+            g_prof_recs.push_back(g_prof_open[i]);
+            g_prof_open.erase(g_prof_open.begin() + (long)i);
+            return;
+        }
+}
+
+IPA_EXPORT int ipa_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_profile_stage_count(void) { return PROF_NSTAGES; }
+
+IPA_EXPORT const char* ipa_profile_stage_name(int stage)
+{
+    static const char* names[PROF_NSTAGES] = {"gray_thresh_pack", "open_vertical",  "open_horizontal",
+                                              "gaussian_blur",    "canny_nms",      "canny_hysteresis",
+                                              "hough_compact",    "hough_vote",     "hough_peaks"};
+    return (stage >= 0 && stage < PROF_NSTAGES) ? names[stage] : "";
+}
+
+IPA_EXPORT int ipa_profile_collect(double* ms, int* launches)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < PROF_NSTAGES; i++) {
+        ms[i] = 0;
+        launches[i] = 0;
+    }
+    for (auto& r : g_prof_recs) {
+        float t = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.stage] += t;
+            launches[r.stage]++;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof_recs.clear();
+    return IPA_OK;
+}
 IPA_EXPORT const char* ipa_last_error(void) { return g_err; }
 IPA_EXPORT size_t ipa_pitch_for(size_t row_bytes) { return align_up(row_bytes ? row_bytes : 1, 256); }
 
@@ -88,18 +163,29 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     int tv = thresh_val < -1 ? -1 : (thresh_val > 256 ? 256 : thresh_val);
 
     // gray + THRESH_BINARY_INV plane + its bit plane, one pass over the BGR input
-    int rc = launch_bgr2gray(B, G, T, bits, bpw, bsw, width, height, batch, tv, 255, 1, st);
+    int rc;
+    {
+        ProfScope ps(PROF_GRAY_THRESH, st);
+        rc = launch_bgr2gray(B, G, T, bits, bpw, bsw, width, height, batch, tv, 255, 1, st);
+    }
     if (rc) return rc;
     // open with (1 x vert_len) and (horiz_len x 1), iterations folded into one larger kernel
     const int KV = vert_len + (iterations - 1) * (vert_len - 1), AV = (vert_len / 2) * iterations;
     const int KH = horiz_len + (iterations - 1) * (horiz_len - 1), AH = (horiz_len / 2) * iterations;
-    rc = launch_bitmorph(bits, bpw, bsw, V, width, height, batch, 0, 2, 1, KV, 0, AV, 255, nullptr, st);
+    {
+        ProfScope ps(PROF_OPEN_V, st);
+        rc = launch_bitmorph(bits, bpw, bsw, V, width, height, batch, 0, 2, 1, KV, 0, AV, 255, nullptr, st);
+    }
     if (rc) return rc;
-    rc = launch_bitmorph(bits, bpw, bsw, H, width, height, batch, 0, 2, KH, 1, AH, 0, 255, nullptr, st);
+    {
+        ProfScope ps(PROF_OPEN_H, st);
+        rc = launch_bitmorph(bits, bpw, bsw, H, width, height, batch, 0, 2, KH, 1, AH, 0, 255, nullptr, st);
+    }
     if (rc) return rc;
     Plane csrc = G;
     if (blur5x5) {
         Plane BL = mkplane(blur_plane, L.blur_pitch, L.blur_pitch * (size_t)height);
+        ProfScope ps(PROF_BLUR, st);
         rc = launch_gauss5(G, BL, width, height, batch, blur_ws, L.blur_ws_bytes, st);
         if (rc) return rc;
         csrc = BL;

@@ -305,9 +305,12 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         if (!g_pinned) IPA_HIP(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
     }
     IPA_HIP(hipMemsetAsync(W.counters, 0, 64, st));
+    prof_begin(PROF_CANNY_NMS, st);
     hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)ntiles), dim3(256), 0, st, src, dst, w, h, tiles_x, tiles_y, low,
                        high, W);
+    prof_end(PROF_CANNY_NMS, st);
     IPA_LAUNCH_CHECK();
+    ProfScope ps(PROF_HYSTERESIS, st);
     const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);
     // pass p reads list (p==1: list0, else ping-pong) and writes the other ping-pong list
     u32 pass = 1;

@@ -99,6 +99,28 @@ struct Arena {
     bool ok() const { return off <= size; }
 };
 
+// ---- optional per-stage timing (HIP events on the caller's stream) --------
+enum ProfStage {
+    PROF_GRAY_THRESH = 0,
+    PROF_OPEN_V,
+    PROF_OPEN_H,
+    PROF_BLUR,
+    PROF_CANNY_NMS,
+    PROF_HYSTERESIS,
+    PROF_HOUGH_COMPACT,
+    PROF_HOUGH_VOTE,
+    PROF_HOUGH_PEAKS,
+    PROF_NSTAGES
+};
+void prof_begin(int stage, hipStream_t st);
+void prof_end(int stage, hipStream_t st);
+struct ProfScope {
+    int stage;
+    hipStream_t st;
+    ProfScope(int s, hipStream_t t) : stage(s), st(t) { prof_begin(s, t); }
+    ~ProfScope() { prof_end(stage, st); }
+};
+
 // ---- internal entry points shared between translation units --------------
 // (all enqueue on `st`; no validation: callers have validated)
 int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bits_pitch_words, size_t bits_stride_words,

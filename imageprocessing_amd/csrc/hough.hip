@@ -261,6 +261,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     }
     IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
     {
+        ProfScope ps(PROF_HOUGH_COMPACT, st);
         int cpr = cdiv(w, 16);
         long long cpi = (long long)cpr * h;
         unsigned gx = (unsigned)((cpi + 255) / 256);
@@ -310,6 +311,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
+    ProfScope ps(PROF_HOUGH_VOTE, st);
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         VoteArgs Ab = A;
@@ -364,6 +366,7 @@ IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, in
     unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
     if (capx < 1) capx = 1;
     if (gx > capx) gx = capx;
+    ProfScope ps(PROF_HOUGH_PEAKS, st);
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         hipLaunchKernelGGL(k_hough_peaks, dim3(gx, nb), dim3(256), 0, st, accum + (size_t)b0 * accum_stride,

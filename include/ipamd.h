@@ -62,6 +62,17 @@ const char* ipa_last_error(void);
 /* Smallest multiple of 256 that is >= row_bytes: the pitch the library prefers. */
 size_t ipa_pitch_for(size_t row_bytes);
 
+/* Optional per-stage timing of the fused front-end (no reference counterpart:
+ * the reference only reports whole-request wall time, umlClassdiagram.py:1096,
+ * 1145-1151).  When enabled, HIP events are recorded on the caller's stream around
+ * every stage; ipa_profile_collect() waits for them and returns, per stage, the
+ * summed milliseconds and the number of timed intervals since the last collect.
+ * Arrays must hold ipa_profile_stage_count() entries. */
+int ipa_profile_enable(int on);
+int ipa_profile_stage_count(void);
+const char* ipa_profile_stage_name(int stage);
+int ipa_profile_collect(double* ms, int* launches);
+
 /* ---- colour conversion ------------------------------------------------- */
 
 /* cv2.cvtColor(img, cv2.COLOR_BGR2GRAY): umlClassdiagram.py:14,1121;

@@ -176,17 +176,27 @@ FR_API double fr_threshold(const u8* src, size_t sp, u8* dst, size_t dp, int w, 
 static void morph_rows(const u8* src, size_t sp, u8* dst, size_t dp, int w, int h, int k, int a,
                        int is_dilate)
 {
-#pragma omp parallel for
-    for (int y = 0; y < h; y++) {
-        const u8* s = src + (size_t)y * sp;
-        u8* d = dst + (size_t)y * dp;
-        for (int x = 0; x < w; x++) {
-            int lo = imax(0, x - a), hi = imin(w - 1, x - a + k - 1);
-            int v = is_dilate ? 0 : 255;
-            for (int i = lo; i <= hi; i++)
-                v = is_dilate ? imax(v, s[i]) : imin(v, s[i]);
-            d[x] = (u8)v;
+    /* row padded with the identity on both sides, then k shifted min/max sweeps */
+    const int padl = a, padr = k - 1 - a;
+#pragma omp parallel
+    {
+        u8* buf = (u8*)malloc((size_t)w + padl + padr + 1);
+#pragma omp for
+        for (int y = 0; y < h; y++) {
+            const u8* s = src + (size_t)y * sp;
+            u8* d = dst + (size_t)y * dp;
+            memset(buf, is_dilate ? 0 : 255, (size_t)w + padl + padr);
+            memcpy(buf + padl, s, (size_t)w);
+            memcpy(d, buf, (size_t)w);
+            for (int i = 1; i < k; i++) {
+                const u8* q = buf + i;
+                if (is_dilate)
+                    for (int x = 0; x < w; x++) d[x] = d[x] > q[x] ? d[x] : q[x];
+                else
+                    for (int x = 0; x < w; x++) d[x] = d[x] < q[x] ? d[x] : q[x];
+            }
         }
+        free(buf);
     }
 }
 
