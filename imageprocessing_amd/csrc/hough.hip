@@ -102,10 +102,45 @@ __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
     return __float2int_rn(__fadd_rn(__fmul_rn(x, c), __fmul_rn(y, s)));
 }
 
-__global__ __launch_bounds__(256) void k_hough_vote(VoteArgs A, Trig T)
+constexpr int VOTE_THREADS = 512;
+constexpr int VOTE_MAX_TG = 16;
+
+// Votes of up to four points for one angle.  idx[] are LDS bin indices (already
+// relative to the first bin held for this angle); consecutive points of the list
+// are usually neighbours on one image row, so equal neighbours are merged into
+// one atomic before they reach the LDS.
+template <bool PACK16>
+__device__ __forceinline__ void vote4(u32* __restrict__ h, const int* idx, const bool* ok, int n)
+{
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k >= n) break;
+        run++;
+        bool last = (k == n - 1) || (idx[k + 1] != idx[k]) || !ok[k + 1];
+        if (last) {
+            if (ok[k]) {
+                if (PACK16)
+                    atomicAdd(&h[idx[k] >> 1], (u32)run << ((idx[k] & 1) * 16));
+                else
+                    atomicAdd(&h[idx[k]], (u32)run);
+            }
+            run = 0;
+        }
+    }
+}
+
+// LDS-privatised voting.  One workgroup = one image x `tg` consecutive angles
+// (x one slice of the rho axis for huge images).  PACK16 packs two 16-bit bins
+// per LDS word (valid while no bin can reach 65536 votes).  The point list is
+// read four points per lane with the next load in flight while the current
+// points vote.
+template <bool PACK16>
+__global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 {
     extern __shared__ __align__(16) u32 hist[];
-    __shared__ int s_col0[64];  // first padded column held in LDS, per angle of the group
+    __shared__ int s_col0[VOTE_MAX_TG];  // first padded column held in LDS, per angle of the group
+    __shared__ float s_cos[VOTE_MAX_TG], s_sin[VOTE_MAX_TG];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int grp = blockIdx.x / A.nseg, seg = blockIdx.x % A.nseg;
@@ -113,6 +148,8 @@ __global__ __launch_bounds__(256) void k_hough_vote(VoteArgs A, Trig T)
     const int tg = min(A.tg, A.numangle - n0);
     const int half = (A.numrho - 1) / 2;
     const int seg_lo = seg * A.seg_cols, seg_hi = min(seg_lo + A.seg_cols, A.numrho + 2);
+    const int span = A.span_max;
+    const int span_words = PACK16 ? (span + 1) >> 1 : span;
 
     if (tid < tg) {
         // smallest reachable rho for this angle: the float ops are monotone, so
@@ -124,20 +161,46 @@ __global__ __launch_bounds__(256) void k_hough_vote(VoteArgs A, Trig T)
         int rmin = min(min(r00, r10), min(r01, r11));
         int col0 = rmin + half + 1;  // padded column of rmin
         s_col0[tid] = max(col0, seg_lo);
+        s_cos[tid] = c;
+        s_sin[tid] = s;
     }
-    for (int i = tid; i < tg * A.span_max; i += 256) hist[i] = 0;
+    for (int i = tid; i < tg * span_words; i += VOTE_THREADS) hist[i] = 0;
     __syncthreads();
 
     const u32 npts = min((u32)A.counts[b], A.cap);
     const u32* pts = A.pts + (size_t)b * A.pts_stride;
-    for (u32 i = tid; i < npts; i += 256) {
-        u32 p = pts[i];
-        float x = (float)(p & 0xffffu), y = (float)(p >> 16);
-        for (int g = 0; g < tg; g++) {
-            int col = rho_index(x, y, T.c[n0 + g], T.s[n0 + g]) + half + 1;
-            int idx = col - s_col0[g];
-            if (col < seg_hi && (unsigned)idx < (unsigned)A.span_max) atomicAdd(&hist[g * A.span_max + idx], 1u);
+    const uint4* pts4 = (const uint4*)pts;
+    const u32 nvec = (npts + 3) >> 2;  // the list buffer is padded to 256 bytes: reading a whole uint4 is safe
+    u32 i = tid;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (i < nvec) cur = pts4[i];
+    while (i < nvec) {
+        const u32 inext = i + VOTE_THREADS;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (inext < nvec) nxt = pts4[inext];
+        const int n = (int)min(4u, npts - i * 4);
+        const u32 p[4] = {cur.x, cur.y, cur.z, cur.w};
+        float x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            x[k] = (float)(p[k] & 0xffffu);
+            y[k] = (float)(p[k] >> 16);
         }
+        for (int g = 0; g < tg; g++) {
+            const float c = s_cos[g], s = s_sin[g];
+            const int c0 = s_col0[g];
+            int idx[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int col = rho_index(x[k], y[k], c, s) + half + 1;
+                idx[k] = col - c0;
+                ok[k] = k < n && col < seg_hi && (unsigned)idx[k] < (unsigned)span;
+            }
+            vote4<PACK16>(hist + g * span_words, idx, ok, n);
+        }
+        cur = nxt;
+        i = inext;
     }
     __syncthreads();
 
@@ -147,15 +210,19 @@ __global__ __launch_bounds__(256) void k_hough_vote(VoteArgs A, Trig T)
     for (int g = 0; g < tg; g++) {
         int32_t* row = acc + (size_t)(n0 + g + 1) * ncols;
         const int c0 = s_col0[g];
-        for (int col = seg_lo + tid; col < seg_hi; col += 256) {
+        const u32* hg = hist + g * span_words;
+        for (int col = seg_lo + tid; col < seg_hi; col += VOTE_THREADS) {
             int idx = col - c0;
-            row[col] = ((unsigned)idx < (unsigned)A.span_max) ? (int32_t)hist[g * A.span_max + idx] : 0;
+            int32_t v = 0;
+            if ((unsigned)idx < (unsigned)span)
+                v = PACK16 ? (int32_t)((hg[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu) : (int32_t)hg[idx];
+            row[col] = v;
         }
     }
     if (grp == 0)
-        for (int col = seg_lo + tid; col < seg_hi; col += 256) acc[col] = 0;
+        for (int col = seg_lo + tid; col < seg_hi; col += VOTE_THREADS) acc[col] = 0;
     if (grp == A.groups - 1)
-        for (int col = seg_lo + tid; col < seg_hi; col += 256) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
+        for (int col = seg_lo + tid; col < seg_hi; col += VOTE_THREADS) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__ accum, size_t accum_stride,
@@ -299,16 +366,23 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         A.seg_cols = cdiv(ncols, A.nseg);
         A.span_max = A.seg_cols;
     }
-    // several angles per workgroup (~48 KiB of LDS) when there are plenty of workgroups anyway
-    int tg = (int)((48 * 1024 / 4) / A.span_max);
+    // 16-bit bins (two per LDS word) while no bin can overflow: a bin never gets more
+    // votes than there are pixels on one line through the image
+    const bool pack16 = ((long long)w + h) < 65535;
+    const int span_words = pack16 ? (A.span_max + 1) / 2 : A.span_max;
+    // several angles per workgroup (up to 64 KiB of LDS: two workgroups per CU) so that
+    // each pass over the point list casts more votes; fewer when the launch would
+    // otherwise have too few workgroups to fill the chip
+    int tg = (int)((64 * 1024 / 4) / span_words);
     if (tg < 1) tg = 1;
-    if (tg > 8) tg = 8;
-    while (tg > 1 && (long long)cdiv(numangle, tg) * batch < 2048) tg--;
+    if (tg > VOTE_MAX_TG) tg = VOTE_MAX_TG;
+    while (tg > 1 && (long long)cdiv(numangle, tg) * A.nseg * batch < 1024) tg--;
     A.tg = tg;
     A.groups = cdiv(numangle, tg);
-    size_t lds = (size_t)tg * A.span_max * 4;
+    size_t lds = (size_t)tg * span_words * 4;
     if (lds > 48 * 1024 && !g_vote_attr_set) {
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
     ProfScope ps(PROF_HOUGH_VOTE, st);
@@ -318,7 +392,10 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.pts = pts + (size_t)b0 * pts_stride;
         Ab.counts = point_counts + b0;
         Ab.accum = accum + (size_t)b0 * accum_stride;
-        hipLaunchKernelGGL(k_hough_vote, dim3((unsigned)(A.groups * A.nseg), nb), dim3(256), lds, st, Ab, T);
+        if (pack16)
+            hipLaunchKernelGGL(k_hough_vote<true>, dim3((unsigned)(A.groups * A.nseg), nb), dim3(VOTE_THREADS), lds, st, Ab, T);
+        else
+            hipLaunchKernelGGL(k_hough_vote<false>, dim3((unsigned)(A.groups * A.nseg), nb), dim3(VOTE_THREADS), lds, st, Ab, T);
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;

@@ -232,6 +232,17 @@ def test_canny_random_and_smooth(h, w):
             assert np.array_equal(a, b), (h, w, lo, hi, int((a != b).sum()))
 
 
+@pytest.mark.parametrize("w", [125, 126, 127, 128, 129, 130, 131, 132, 133, 257])
+def test_canny_dense_weak_fields_at_every_width_phase(w):
+    # low threshold ~0: nearly every pixel is a candidate, few are strong -> the hysteresis
+    # walk, its queue overflow path and the image-border handling all get exercised
+    g = rand_gray(w, 70, w)
+    for lo, hi in ((10, 400), (0, 300), (10, 10), (5, 700)):
+        a = cv2.Canny(g, lo, hi)
+        b = fr.canny(g, lo, hi)
+        assert np.array_equal(a, b), (w, lo, hi, int((a != b).sum()))
+
+
 def test_canny_reference_images(cd_bgr, login_bgr):
     for bgr in (cd_bgr, login_bgr):
         g = fr.bgr2gray(bgr)
