@@ -5,13 +5,10 @@
 //                suppression -> edge bytes: 255 above the high threshold, WEAK
 //                for candidates between the thresholds, 0 otherwise.  Tiles that
 //                hold WEAK pixels are flagged.
-//  k_hyst_dfs  : hysteresis.  One workgroup owns one image (or one region of a
-//                huge image), scans the flagged tiles for WEAK pixels that touch
-//                an edge pixel, promotes them with an atomic OR and walks the
-//                chain depth-first from there (private LDS stack per lane).
-//                Every promotion is an atomic read-modify-write and values only
-//                ever go WEAK -> 255, so walks may cross into other workgroups'
-//                regions and stale plain reads are harmless.
+//  k_hyst_tiles: hysteresis.  One workgroup owns one image (or one region of a
+//                huge image) and works through rounds of a tile worklist; a wave
+//                resolves one tile in registers (bit masks + lane shuffles) and
+//                queues the neighbours when its rim changed.
 //  k_hyst_final: remaining WEAK bytes -> 0.
 //
 // The result does not depend on processing order: a candidate survives iff its
@@ -191,200 +188,188 @@ __global__ __launch_bounds__(256) void k_canny_nms(Plane src, Plane dst, int w, 
     if (tid == 0) W.has_weak[blockIdx.x] = s_weak ? 1 : 0;
 }
 
-constexpr int DFS_THREADS = 512;
-constexpr int DFS_DEPTH = 16;
-constexpr int DFS_QCAP = 2048;
-constexpr int DFS_SCAN_STEPS = 4;
-constexpr int DFS_MAX_TILES = 4096;  // tiles per region
+constexpr int HT_THREADS = 512;      // 8 waves per workgroup
+constexpr int HT_MAX_TILES = 4096;   // tiles per region (one workgroup)
 
-// L2-served load (bypasses the per-CU L1) of the aligned word holding byte (x) of a row
-__device__ __forceinline__ u32 load_word_l2(const u8* row, int x)
-{
-    return __hip_atomic_load((const u32*)(row + (x & ~3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u32 byte_at(const u8* row, int x) { return (load_word_l2(row, x) >> (8 * (x & 3))) & 0xffu; }
+// bit 0 of each of the 4 bytes of x -> 4 adjacent bits
+__device__ __forceinline__ u32 gather4(u32 x) { return ((x & 0x01010101u) * 0x10204080u) >> 28; }
 
-// WEAK -> 255 with an atomic OR; true iff this lane made the change
-__device__ __forceinline__ bool promote(u8* row, int x)
-{
-    const u32 sh = 8u * (u32)(x & 3);
-    u32 old = atomicOr((u32*)(row + (x & ~3)), 0xffu << sh);
-    return ((old >> sh) & 0xffu) == WEAK;
-}
+struct TileBits {
+    u64 S, W;  // edge / WEAK masks of this lane's 64 pixels (bit i = pixel i)
+};
 
-// The 3x3 neighbourhood of (x, y) as three 24-bit values (bytes x-1, x, x+1 of rows y-1,
-// y, y+1; 0 outside the image).  All word loads are issued before the first use.
-__device__ __forceinline__ void load_3x3(const Plane& dst, int b, int x, int y, int w, int h, u32 out[3])
+// edge bytes of 64 consecutive pixels -> masks.  Pixels at or beyond `nvalid` are empty.
+__device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
 {
-    const int xl = x - 1, xr = x + 1;
-    u32 lo[3], hi[3];
+    TileBits t;
+    t.S = 0;
+    t.W = 0;
+    if (nvalid <= 0) return t;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int ny = y + k - 1;
-        lo[k] = hi[k] = 0;
-        if (ny >= 0 && ny < h) {
-            const u8* row = dst.row(b, ny);
-            // lo = word of x-1, hi = word of min(x+1, w-1): between them they always hold x
-            const int xc = xr < w ? xr : x;
-            if (xl >= 0) lo[k] = load_word_l2(row, xl);
-            hi[k] = ((xc & ~3) == (xl & ~3) && xl >= 0) ? lo[k] : load_word_l2(row, xc);
+    for (int q = 0; q < 4; q++) {
+        if (q * 16 >= nvalid) break;
+        const uint4 v = *(const uint4*)(p + 16 * q);
+        const u32 d[4] = {v.x, v.y, v.z, v.w};
+        u32 s16 = 0, w16 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 top = d[k] >> 7;
+            s16 |= gather4(top) << (4 * k);
+            w16 |= gather4(d[k] & ~top) << (4 * k);
         }
+        t.S |= (u64)s16 << (16 * q);
+        t.W |= (u64)w16 << (16 * q);
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        u32 l = xl >= 0 ? (lo[k] >> (8 * (xl & 3))) & 0xffu : 0u;
-        u32 r = xr < w ? (hi[k] >> (8 * (xr & 3))) & 0xffu : 0u;
-        // centre byte: in the word of x-1 or of x+1
-        u32 cw = ((x & ~3) == (xl & ~3) && xl >= 0) ? lo[k] : hi[k];
-        u32 c = (cw >> (8 * (x & 3))) & 0xffu;
-        out[k] = l | (c << 8) | (r << 16);
+    if (nvalid < 64) {
+        const u64 m = (1ull << nvalid) - 1ull;
+        t.S &= m;
+        t.W &= m;
     }
+    return t;
 }
 
-// Promote (x, y) if it is WEAK and walk the chain of WEAK pixels reachable from it.
-// Returns true if some promoted pixel could not be pushed (its neighbours are then
-// found by the next scan).
-__device__ __forceinline__ bool dfs_from(const Plane& dst, int b, int x, int y, int w, int h, u32* stack)
+// Hysteresis on tiles.  One workgroup owns one image (or one region of a huge image) and
+// works through rounds of a tile worklist held in LDS; the first round holds every tile
+// that has WEAK pixels.  One wave resolves one 128x32 tile at a time entirely in
+// registers: lane = (row, 64-pixel half), the edge / WEAK state as two 64-bit masks, a
+// 1-pixel ring of the neighbours' edge bits around it, and a fixed point of
+//     S |= W & dilate3x3(S)
+// with row neighbours exchanged by lane shuffles.  Promoted pixels are written back with
+// atomic ORs; if the rim of the tile changed, the neighbouring tiles with WEAK pixels go on
+// the next round's list.  Rounds are separated by a workgroup barrier (which also drains
+// the stores) and an L1 invalidate, so a round sees everything the previous one wrote.
+__global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
+                                                           int rt_x, int rt_y, int regions_x, int regions_y,
+                                                           CannyWs W)
 {
-    bool dropped = false;
-    if (!promote(dst.row(b, y), x)) return false;
-    int sp = 0;
-    stack[sp++] = ((u32)y << 16) | (u32)x;
-    while (sp) {
-        const u32 p = stack[--sp];
-        const int py = (int)(p >> 16), px = (int)(p & 0xffffu);
-        u32 nb[3];
-        load_3x3(dst, b, px, py, w, h, nb);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                if (k == 1 && j == 1) continue;
-                if (((nb[k] >> (8 * j)) & 0xffu) != WEAK) continue;
-                const int ny = py + k - 1, nx = px + j - 1;
-                if (promote(dst.row(b, ny), nx)) {
-                    if (sp < DFS_DEPTH) stack[sp++] = ((u32)ny << 16) | (u32)nx;
-                    else dropped = true;
-                }
-            }
-        }
-    }
-    return dropped;
-}
-
-// One workgroup = one image (or one region of a huge image).  Rounds of: scan a batch
-// of flagged tiles for WEAK pixels (queued in LDS), then every lane takes queued
-// pixels, tests whether an edge pixel touches them and if so walks the chain.
-__global__ __launch_bounds__(DFS_THREADS) void k_hyst_dfs(Plane dst, int w, int h, int tiles_x, int tiles_y, int rt_x,
-                                                          int rt_y, int regions_x, int regions_y, CannyWs W)
-{
-    __shared__ u32 s_stack[DFS_THREADS * DFS_DEPTH];
-    __shared__ u32 s_tiles[DFS_MAX_TILES];
-    __shared__ u32 s_q[DFS_QCAP];
-    __shared__ u32 s_ntiles, s_qn;
-    __shared__ int s_overflow;
-    const int tid = threadIdx.x;
+    __shared__ u16 s_list[2][HT_MAX_TILES];
+    __shared__ u32 s_inq[HT_MAX_TILES / 32];
+    __shared__ u32 s_flag[HT_MAX_TILES / 32];
+    __shared__ u32 s_cnt[2];
+    __shared__ u32 s_cursor;
+    const int tid = threadIdx.x, lane = tid & 63;
     int blk = blockIdx.x;
     const int rx = blk % regions_x;
     blk /= regions_x;
     const int ry = blk % regions_y, b = blk / regions_y;
+    const int tx_base = rx * rt_x, ty_base = ry * rt_y;
+    const int nx_t = min(rt_x, tiles_x - tx_base), ny_t = min(rt_y, tiles_y - ty_base);
+
+    for (int i = tid; i < HT_MAX_TILES / 32; i += HT_THREADS) {
+        s_inq[i] = 0;
+        s_flag[i] = 0;
+    }
     if (tid == 0) {
-        s_ntiles = 0;
-        s_qn = 0;
-        s_overflow = 0;
+        s_cnt[0] = 0;
+        s_cnt[1] = 0;
+        s_cursor = 0;
     }
     __syncthreads();
-    for (int t = tid; t < rt_x * rt_y; t += DFS_THREADS) {
-        int tx = rx * rt_x + t % rt_x, ty = ry * rt_y + t / rt_x;
-        if (tx < tiles_x && ty < tiles_y && W.has_weak[((size_t)b * tiles_y + ty) * tiles_x + tx]) {
-            u32 pos = atomicAdd(&s_ntiles, 1u);
-            s_tiles[pos] = ((u32)ty << 16) | (u32)tx;
+    for (int t = tid; t < nx_t * ny_t; t += HT_THREADS) {
+        const int lx = t % nx_t, ly = t / nx_t;
+        if (W.has_weak[((size_t)b * tiles_y + ty_base + ly) * tiles_x + tx_base + lx]) {
+            atomicOr(&s_flag[t >> 5], 1u << (t & 31));
+            const u32 pos = atomicAdd(&s_cnt[0], 1u);
+            s_list[0][pos] = (u16)t;
         }
     }
     __syncthreads();
-    const u32 ntiles = s_ntiles;
-    if (ntiles == 0) return;
-    u32* stack = s_stack + tid * DFS_DEPTH;
-    // scan geometry: a tile is 256 chunks of 16 pixels; 512 lanes cover 2 tiles per step,
-    // DFS_SCAN_STEPS steps (independent loads) per batch
-    const int half = tid >> 8, l = tid & 255;
-    const int lr = l >> 3, lc0 = (l & 7) * 16;
-    constexpr int TILES_PER_BATCH = 2 * DFS_SCAN_STEPS;
-    for (int round = 0; round < (1 << 20); round++) {
-        bool dropped = false;
-        for (u32 t0 = 0; t0 < ntiles; t0 += TILES_PER_BATCH) {
-            // ---- scan
-            u32 d[DFS_SCAN_STEPS][4];
-            int ys[DFS_SCAN_STEPS], xs[DFS_SCAN_STEPS];
-#pragma unroll
-            for (int s = 0; s < DFS_SCAN_STEPS; s++) {
-                const u32 ti = t0 + 2 * s + half;
-                ys[s] = -1;
-                xs[s] = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) d[s][k] = 0;
-                if (ti < ntiles) {
-                    const u32 tile = s_tiles[ti];
-                    const int iy = (int)(tile >> 16) * TH + lr, ix0 = (int)(tile & 0xffffu) * TW + lc0;
-                    if (iy < h && ix0 < w) {
-                        const u8* row = dst.row(b, iy);
-                        ys[s] = iy;
-                        xs[s] = ix0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) d[s][k] = load_word_l2(row, ix0 + 4 * k);
-                    }
+
+    const int r = lane >> 1, hf = lane & 1;
+    int cur = 0;
+    for (int round = 0; round < (1 << 24); round++) {
+        const u32 n = s_cnt[cur];
+        if (n == 0) break;
+        const int nxt = cur ^ 1;
+        for (;;) {
+            u32 i = 0;
+            if (lane == 0) i = atomicAdd(&s_cursor, 1u);
+            i = __shfl(i, 0);
+            if (i >= n) break;
+            const int t = s_list[cur][i];
+            const int lx = t % nx_t, ly = t / nx_t;
+            const int x0 = (tx_base + lx) * TW, y0 = (ty_base + ly) * TH;
+            const int iy = y0 + r, xh = x0 + 64 * hf;
+            // own 64 pixels
+            TileBits me;
+            me.S = me.W = 0;
+            if (iy < h) me = load_bits64(dst.row(b, iy) + xh, w - xh);
+            // the edge bit just outside this lane's end of the row (ring column)
+            const int xs = hf ? x0 + TW : x0 - 1;
+            u32 side = 0;
+            if (iy < h && xs >= 0 && xs < w) side = dst.row(b, iy)[xs] >> 7;
+            // ring rows: lanes of row 0 hold the row above the tile, lanes of row 31 the row below
+            u64 ringS = 0;
+            u32 ring_side = 0;
+            const int ry_ = r == 0 ? y0 - 1 : y0 + TH;
+            if ((r == 0 || r == TH - 1) && ry_ >= 0 && ry_ < h) {
+                ringS = load_bits64(dst.row(b, ry_) + xh, w - xh).S;
+                if (xs >= 0 && xs < w) ring_side = dst.row(b, ry_)[xs] >> 7;
+            }
+            // horizontally dilated ring row (constant during the iteration)
+            u64 ringH;
+            {
+                const u64 pr = __shfl_xor(ringS, 1);
+                const u64 lin = hf ? (pr >> 63) : (u64)ring_side;
+                const u64 rin = hf ? (u64)ring_side : (pr & 1ull);
+                ringH = ringS | (ringS << 1) | (ringS >> 1) | lin | (rin << 63);
+            }
+            const u64 S0 = me.S;
+            u64 S = me.S;
+            if (__any(me.W != 0)) {
+                for (;;) {
+                    const u64 pS = __shfl_xor(S, 1);
+                    const u64 lin = hf ? (pS >> 63) : (u64)side;
+                    const u64 rin = hf ? (u64)side : (pS & 1ull);
+                    const u64 H = S | (S << 1) | (S >> 1) | lin | (rin << 63);
+                    u64 up = __shfl_up(H, 2), dn = __shfl_down(H, 2);
+                    if (r == 0) up = ringH;
+                    if (r == TH - 1) dn = ringH;
+                    const u64 Sn = S | (me.W & (H | up | dn));
+                    const bool ch = Sn != S;
+                    S = Sn;
+                    if (!__any(ch)) break;
                 }
             }
+            const u64 prom = S & ~S0;
+            if (prom) {
+                u8* row = dst.row(b, iy) + xh;
 #pragma unroll
-            for (int s = 0; s < DFS_SCAN_STEPS; s++) {
-                if (ys[s] < 0) continue;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    u32 v = d[s][k];
-                    if (v == 0u || v == 0xffffffffu) continue;
-                    for (int j = 0; j < 4; j++) {
-                        if (((v >> (8 * j)) & 0xffu) != WEAK) continue;
-                        const int x = xs[s] + 4 * k + j;
-                        if (x >= w) continue;
-                        u32 pos = atomicAdd(&s_qn, 1u);
-                        if (pos < DFS_QCAP) s_q[pos] = ((u32)ys[s] << 16) | (u32)x;
-                        else {
-                            // queue full (a noise field): handle it here
-                            u32 nb[3];
-                            load_3x3(dst, b, x, ys[s], w, h, nb);
-                            if ((((nb[0] | nb[2]) & 0x808080u) | (nb[1] & 0x800080u)) != 0u)
-                                dropped |= dfs_from(dst, b, x, ys[s], w, h, stack);
+                for (int q = 0; q < 16; q++) {
+                    const u32 nib = (u32)(prom >> (4 * q)) & 0xfu;
+                    if (nib) atomicOr((u32*)(row + 4 * q), ((nib * 0x00204081u) & 0x01010101u) * 0xffu);
+                }
+            }
+            // rim changed -> neighbours with WEAK pixels are due in the next round
+            const bool rim = prom && (r == 0 || r == TH - 1 || (hf == 0 && (prom & 1ull)) || (hf == 1 && (prom >> 63)));
+            if (__any(rim) && lane < 9 && lane != 4) {
+                const int nlx = lx + (lane % 3) - 1, nly = ly + (lane / 3) - 1;
+                const int gtx = tx_base + nlx, gty = ty_base + nly;
+                if (gtx >= 0 && gtx < tiles_x && gty >= 0 && gty < tiles_y) {
+                    if (nlx >= 0 && nlx < nx_t && nly >= 0 && nly < ny_t) {
+                        const int nt = nly * nx_t + nlx;
+                        if ((s_flag[nt >> 5] >> (nt & 31)) & 1u) {
+                            const u32 old = atomicOr(&s_inq[nt >> 5], 1u << (nt & 31));
+                            if (!((old >> (nt & 31)) & 1u)) {
+                                const u32 pos = atomicAdd(&s_cnt[nxt], 1u);
+                                s_list[nxt][pos] = (u16)nt;
+                            }
                         }
+                    } else if (W.has_weak[((size_t)b * tiles_y + gty) * tiles_x + gtx]) {
+                        atomicExch(W.again, 1u);  // belongs to another workgroup's region: one more launch
                     }
                 }
             }
-            __syncthreads();
-            // ---- resolve the queued pixels
-            const u32 qn = min(s_qn, (u32)DFS_QCAP);
-            for (u32 i = tid; i < qn; i += DFS_THREADS) {
-                const u32 p = s_q[i];
-                const int y = (int)(p >> 16), x = (int)(p & 0xffffu);
-                u32 nb[3];
-                load_3x3(dst, b, x, y, w, h, nb);
-                // bytes are 0, WEAK (1) or 255: an edge pixel touches iff some neighbour has its top bit set
-                if ((((nb[0] | nb[2]) & 0x808080u) | (nb[1] & 0x800080u)) != 0u)
-                    dropped |= dfs_from(dst, b, x, y, w, h, stack);
-            }
-            __syncthreads();
-            if (tid == 0) s_qn = 0;
-            __syncthreads();
         }
-        if (dropped) s_overflow = 1;
-        __syncthreads();
-        const int again = s_overflow;
-        __syncthreads();
-        if (!again) break;
+        __syncthreads();  // also waits for this round's stores and atomics
         if (tid == 0) {
-            s_overflow = 0;
-            // a dropped pixel may border another region: ask for one more launch
-            if (regions_x * regions_y > 1) atomicExch(W.again, 1u);
+            s_cnt[cur] = 0;
+            s_cursor = 0;
         }
+        for (int i = tid; i < HT_MAX_TILES / 32; i += HT_THREADS) s_inq[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before re-reading tiles
         __syncthreads();
+        cur = nxt;
     }
 }
 
@@ -427,7 +412,7 @@ size_t canny_ws_bytes(int w, int h, int batch)
     return align_up(ntiles, 256) + 512;
 }
 
-// Enqueues the whole detector.  Images of up to DFS_MAX_TILES tiles (e.g. 4K) are
+// Enqueues the whole detector.  Images of up to HT_MAX_TILES tiles (e.g. 4K) are
 // resolved by one workgroup each with no host interaction; larger images are cut
 // into regions and the stream is synchronised to learn whether a further
 // hysteresis launch is needed.
@@ -450,11 +435,11 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         IPA_LAUNCH_CHECK();
     }
     ProfScope ps(PROF_HYSTERESIS, st);
-    // regions of at most DFS_MAX_TILES tiles (64 x 64 tiles = 8192 x 2048 pixels)
+    // regions of at most HT_MAX_TILES tiles (64 x 64 tiles = 8192 x 2048 pixels)
     int rt_x = tiles_x, rt_y = tiles_y;
-    if ((long long)rt_x * rt_y > DFS_MAX_TILES) {
+    if ((long long)rt_x * rt_y > HT_MAX_TILES) {
         rt_x = tiles_x < 64 ? tiles_x : 64;
-        rt_y = DFS_MAX_TILES / rt_x;
+        rt_y = HT_MAX_TILES / rt_x;
         if (rt_y > tiles_y) rt_y = tiles_y;
     }
     const int regions_x = cdiv(tiles_x, rt_x), regions_y = cdiv(tiles_y, rt_y);
@@ -463,7 +448,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     const bool multi = regions_x * regions_y > 1;
     for (int guard = 0; guard < 100000; guard++) {
         if (multi) IPA_HIP(hipMemsetAsync(W.again, 0, 4, st));
-        hipLaunchKernelGGL(k_hyst_dfs, dim3((unsigned)blocks), dim3(DFS_THREADS), 0, st, dst, w, h, tiles_x, tiles_y, rt_x,
+        hipLaunchKernelGGL(k_hyst_tiles, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x, tiles_y, rt_x,
                            rt_y, regions_x, regions_y, W);
         IPA_LAUNCH_CHECK();
         if (!multi) break;

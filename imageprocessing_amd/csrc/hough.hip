@@ -16,6 +16,7 @@
 #include "common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -105,37 +106,26 @@ __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
 constexpr int VOTE_THREADS = 512;
 constexpr int VOTE_MAX_TG = 16;
 
-// Votes of up to four points for one angle.  idx[] are LDS bin indices (already
-// relative to the first bin held for this angle); consecutive points of the list
-// are usually neighbours on one image row, so equal neighbours are merged into
-// one atomic before they reach the LDS.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// One vote.  PACK16 packs two 16-bit bins per LDS word.
 template <bool PACK16>
-__device__ __forceinline__ void vote4(u32* __restrict__ h, const int* idx, const bool* ok, int n)
+__device__ __forceinline__ void vote1(u32* __restrict__ h, int idx)
 {
-    int run = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k >= n) break;
-        run++;
-        bool last = (k == n - 1) || (idx[k + 1] != idx[k]) || !ok[k + 1];
-        if (last) {
-            if (ok[k]) {
-                if (PACK16)
-                    atomicAdd(&h[idx[k] >> 1], (u32)run << ((idx[k] & 1) * 16));
-                else
-                    atomicAdd(&h[idx[k]], (u32)run);
-            }
-            run = 0;
-        }
-    }
+    if (PACK16)
+        atomicAdd(&h[idx >> 1], 1u << ((idx & 1) * 16));
+    else
+        atomicAdd(&h[idx], 1u);
 }
 
 // LDS-privatised voting.  One workgroup = one image x `tg` consecutive angles
 // (x one slice of the rho axis for huge images).  PACK16 packs two 16-bit bins
-// per LDS word (valid while no bin can reach 65536 votes).  The point list is
-// read four points per lane with the next load in flight while the current
-// points vote.
-template <bool PACK16>
+// per LDS word (valid while no bin can reach 65536 votes).  CHECK adds the range
+// test needed only when the rho axis is sliced.  The point list is read four
+// points per lane with the next load in flight while the current points vote;
+// rho for two points at a time with packed float multiplies/adds (each still
+// rounded separately, as the scalar form).
+template <bool PACK16, bool CHECK>
 __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 {
     extern __shared__ __align__(16) u32 hist[];
@@ -170,37 +160,54 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
     const u32 npts = min((u32)A.counts[b], A.cap);
     const u32* pts = A.pts + (size_t)b * A.pts_stride;
     const uint4* pts4 = (const uint4*)pts;
-    const u32 nvec = (npts + 3) >> 2;  // the list buffer is padded to 256 bytes: reading a whole uint4 is safe
+    const u32 nfull = npts >> 2;  // whole groups of four points
     u32 i = tid;
     uint4 cur = make_uint4(0, 0, 0, 0);
-    if (i < nvec) cur = pts4[i];
-    while (i < nvec) {
+    if (i < nfull) cur = pts4[i];
+    while (i < nfull) {
         const u32 inext = i + VOTE_THREADS;
         uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (inext < nvec) nxt = pts4[inext];
-        const int n = (int)min(4u, npts - i * 4);
-        const u32 p[4] = {cur.x, cur.y, cur.z, cur.w};
-        float x[4], y[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            x[k] = (float)(p[k] & 0xffffu);
-            y[k] = (float)(p[k] >> 16);
-        }
+        if (inext < nfull) nxt = pts4[inext];
+        const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
+        const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
+        const f2 y01 = {(float)(cur.x >> 16), (float)(cur.y >> 16)};
+        const f2 y23 = {(float)(cur.z >> 16), (float)(cur.w >> 16)};
         for (int g = 0; g < tg; g++) {
             const float c = s_cos[g], s = s_sin[g];
-            const int c0 = s_col0[g];
-            int idx[4];
-            bool ok[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int col = rho_index(x[k], y[k], c, s) + half + 1;
-                idx[k] = col - c0;
-                ok[k] = k < n && col < seg_hi && (unsigned)idx[k] < (unsigned)span;
+            u32* hg = hist + g * span_words;
+            // round-half-even through the float adder: for |r| < 2^22 the sum r + 1.5*2^23 is
+            // rounded to an integer and its low mantissa bits hold that integer
+            const f2 magic = {12582912.0f, 12582912.0f};
+            const int off = half + 1 - s_col0[g] - 0x4B400000;
+            const f2 r01 = (x01 * c + y01 * s) + magic;  // -ffp-contract=off: every op rounds on its own
+            const f2 r23 = (x23 * c + y23 * s) + magic;
+            const int i0 = __float_as_int(r01.x) + off, i1 = __float_as_int(r01.y) + off;
+            const int i2 = __float_as_int(r23.x) + off, i3 = __float_as_int(r23.y) + off;
+            if (CHECK) {
+                const int lim = min(span, seg_hi - s_col0[g]);
+                if ((unsigned)i0 < (unsigned)lim) vote1<PACK16>(hg, i0);
+                if ((unsigned)i1 < (unsigned)lim) vote1<PACK16>(hg, i1);
+                if ((unsigned)i2 < (unsigned)lim) vote1<PACK16>(hg, i2);
+                if ((unsigned)i3 < (unsigned)lim) vote1<PACK16>(hg, i3);
+            } else {
+                vote1<PACK16>(hg, i0);
+                vote1<PACK16>(hg, i1);
+                vote1<PACK16>(hg, i2);
+                vote1<PACK16>(hg, i3);
             }
-            vote4<PACK16>(hist + g * span_words, idx, ok, n);
         }
         cur = nxt;
         i = inext;
+    }
+    // the last 0..3 points
+    for (u32 j = nfull * 4 + tid; j < npts; j += VOTE_THREADS) {
+        const u32 p = pts[j];
+        const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
+        for (int g = 0; g < tg; g++) {
+            const int idx = rho_index(x, y, s_cos[g], s_sin[g]) + half + 1 - s_col0[g];
+            const int lim = min(span, seg_hi - s_col0[g]);
+            if ((unsigned)idx < (unsigned)lim) vote1<PACK16>(hist + g * span_words, idx);
+        }
     }
     __syncthreads();
 
@@ -368,12 +375,25 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     }
     // 16-bit bins (two per LDS word) while no bin can overflow: a bin never gets more
     // votes than there are pixels on one line through the image
-    const bool pack16 = ((long long)w + h) < 65535;
+    static int mode = -1;  // IPA_VOTE_MODE: 0 = 32-bit bins (default, fewest instructions per vote), 1 = 16-bit bins
+    if (mode < 0) {
+        const char* e = getenv("IPA_VOTE_MODE");
+        mode = e ? atoi(e) : 0;
+    }
+    const bool pack16 = ((long long)w + h) < 65535 && mode == 1;
+    const bool check = A.nseg > 1;
     const int span_words = pack16 ? (A.span_max + 1) / 2 : A.span_max;
     // several angles per workgroup (up to 64 KiB of LDS: two workgroups per CU) so that
     // each pass over the point list casts more votes; fewer when the launch would
     // otherwise have too few workgroups to fill the chip
-    int tg = (int)((64 * 1024 / 4) / span_words);
+    static int lds_kb = -1;  // IPA_VOTE_LDS_KB: LDS budget per workgroup
+    if (lds_kb < 0) {
+        const char* e = getenv("IPA_VOTE_LDS_KB");
+        lds_kb = e ? atoi(e) : 78;
+        if (lds_kb < 8) lds_kb = 8;
+        if (lds_kb > 150) lds_kb = 150;
+    }
+    int tg = (int)(((size_t)lds_kb * 1024 / 4) / span_words);
     if (tg < 1) tg = 1;
     if (tg > VOTE_MAX_TG) tg = VOTE_MAX_TG;
     while (tg > 1 && (long long)cdiv(numangle, tg) * A.nseg * batch < 1024) tg--;
@@ -381,8 +401,10 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     A.groups = cdiv(numangle, tg);
     size_t lds = (size_t)tg * span_words * 4;
     if (lds > 48 * 1024 && !g_vote_attr_set) {
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
     ProfScope ps(PROF_HOUGH_VOTE, st);
@@ -392,10 +414,15 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.pts = pts + (size_t)b0 * pts_stride;
         Ab.counts = point_counts + b0;
         Ab.accum = accum + (size_t)b0 * accum_stride;
-        if (pack16)
-            hipLaunchKernelGGL(k_hough_vote<true>, dim3((unsigned)(A.groups * A.nseg), nb), dim3(VOTE_THREADS), lds, st, Ab, T);
+        const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
+        if (pack16 && !check)
+            hipLaunchKernelGGL((k_hough_vote<true, false>), grid, block, lds, st, Ab, T);
+        else if (pack16)
+            hipLaunchKernelGGL((k_hough_vote<true, true>), grid, block, lds, st, Ab, T);
+        else if (!check)
+            hipLaunchKernelGGL((k_hough_vote<false, false>), grid, block, lds, st, Ab, T);
         else
-            hipLaunchKernelGGL(k_hough_vote<false>, dim3((unsigned)(A.groups * A.nseg), nb), dim3(VOTE_THREADS), lds, st, Ab, T);
+            hipLaunchKernelGGL((k_hough_vote<false, true>), grid, block, lds, st, Ab, T);
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;

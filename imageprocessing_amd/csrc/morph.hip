@@ -14,6 +14,8 @@
 // pass with k' = k + (n-1)(k-1), a' = a*n.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace {
 
 // ------------------------------------------------------------------ bit planes
@@ -221,6 +223,200 @@ __global__ __launch_bounds__(256) void k_bitmorph(BitMorphArgs A)
     }
 }
 
+// ---- register-level bit-plane kernels (the production shapes) ---------------------
+
+__device__ __forceinline__ void expand16(u32 hbits, u32 value, u8* out)
+{
+    u32 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u32 nib = (hbits >> (4 * q)) & 0xfu;
+        o[q] = ((nib * 0x00204081u) & 0x01010101u) * value;
+    }
+    *(uint4*)out = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+struct Win3 {
+    u32 a0, a1, a2;  // 96 consecutive pixels: a0 = lowest x
+};
+
+// window seen `d` pixels to the right (d in 1..31): out[p] = in[p + d]; `fill` enters at the top
+__device__ __forceinline__ Win3 look_right(Win3 v, int d, u32 fill)
+{
+    Win3 r;
+    r.a0 = __builtin_amdgcn_alignbit(v.a1, v.a0, d);
+    r.a1 = __builtin_amdgcn_alignbit(v.a2, v.a1, d);
+    r.a2 = __builtin_amdgcn_alignbit(fill, v.a2, d);
+    return r;
+}
+// window seen `d` pixels to the left (d in 1..31): out[p] = in[p - d]
+__device__ __forceinline__ Win3 look_left(Win3 v, int d, u32 fill)
+{
+    Win3 r;
+    r.a2 = __builtin_amdgcn_alignbit(v.a2, v.a1, 32 - d);
+    r.a1 = __builtin_amdgcn_alignbit(v.a1, v.a0, 32 - d);
+    r.a0 = __builtin_amdgcn_alignbit(v.a0, fill, 32 - d);
+    return r;
+}
+// out[p] = in[p + d] for d in [-32, 32]
+__device__ __forceinline__ Win3 look(Win3 v, int d, u32 fill)
+{
+    if (d == 0) return v;
+    if (d == 32) { Win3 r; r.a0 = v.a1; r.a1 = v.a2; r.a2 = fill; return r; }
+    if (d == -32) { Win3 r; r.a0 = fill; r.a1 = v.a0; r.a2 = v.a1; return r; }
+    return d > 0 ? look_right(v, d, fill) : look_left(v, -d, fill);
+}
+__device__ __forceinline__ Win3 comb3(Win3 a, Win3 b, bool dil)
+{
+    Win3 r;
+    r.a0 = comb(a.a0, b.a0, dil); r.a1 = comb(a.a1, b.a1, dil); r.a2 = comb(a.a2, b.a2, dil);
+    return r;
+}
+
+// Horizontal erode / dilate / open / close of a bit plane whose whole reach fits in the
+// neighbouring words (nops*ax <= 32 and nops*(kx-1-ax) <= 32: e.g. the 29-pixel line
+// kernel of the parsers).  One lane = 16 output pixels (one 16-byte store); it holds
+// words j-1, j, j+1 of its row in registers and runs the doubling steps there.
+__global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
+                                                     int w, int h, int cpr, long long total, int first_is_dilate,
+                                                     int nops, int kx, int ax, int px, u32 value,
+                                                     const int32_t* __restrict__ value_dev)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int words = (w + 31) >> 5;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        const int cx = (int)(c % cpr);
+        long long t = c / cpr;
+        const int y = (int)(t % h), b = (int)(t / h);
+        const int j = cx >> 1;
+        const u32* row = bits + (size_t)b * bsw + (size_t)y * bpw;
+        // in-image masks of the three words
+        Win3 m;
+        m.a0 = j >= 1 ? 0xffffffffu : 0u;
+        {
+            int rem = w - 32 * j;
+            m.a1 = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+            rem -= 32;
+            m.a2 = rem >= 32 ? 0xffffffffu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+        }
+        Win3 v;
+        v.a0 = j >= 1 ? row[j - 1] : 0u;
+        v.a1 = row[j];
+        v.a2 = j + 1 < words ? row[j + 1] : 0u;
+        bool dil = first_is_dilate != 0;
+        for (int stage = 0; stage < nops; stage++) {
+            const u32 ident = dil ? 0u : 0xffffffffu;
+            // pixels outside the image take the identity of this stage
+            v.a0 = (v.a0 & m.a0) | (ident & ~m.a0);
+            v.a1 = (v.a1 & m.a1) | (ident & ~m.a1);
+            v.a2 = (v.a2 & m.a2) | (ident & ~m.a2);
+            for (int mm = 1; mm < px; mm <<= 1) v = comb3(v, look_right(v, mm, ident), dil);
+            v = comb3(look(v, -ax, ident), look(v, kx - px - ax, ident), dil);
+            dil = !dil;
+        }
+        const u32 val = value_dev ? (u32)value_dev[b] : value;
+        expand16((v.a1 >> ((cx & 1) * 16)) & 0xffffu, val, dst.row(b, y) + (size_t)cx * 16);
+    }
+}
+
+// Bit-sliced run counter: `d` (n slices) = how many more consecutive 1-rows are needed for a
+// full window of k; one update per row.  Returns the mask of columns whose window is full.
+template <int NS>
+__device__ __forceinline__ u32 run_update(u32 (&d)[NS], u32 in, int k)
+{
+    // decrement where non-zero
+    u32 nz = d[0];
+#pragma unroll
+    for (int i = 1; i < NS; i++) nz |= d[i];
+    u32 borrow = nz;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        const u32 di = d[i];
+        d[i] = di ^ borrow;
+        borrow &= ~di;
+    }
+    // reload k where the input row is 0
+    const u32 nin = ~in;
+    u32 any = 0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        d[i] = ((k >> i) & 1) ? (d[i] | nin) : (d[i] & in);
+        any |= d[i];
+    }
+    return ~any;
+}
+
+// Vertical erode / dilate / open / close of a bit plane (kx == 1, any ky < 2^NS).  One lane
+// streams one 32-pixel word column down a strip of rows; the k-row window is a bit-sliced
+// run counter per stage, so the cost per row does not depend on k and nothing but the
+// counters is kept.  A dilation is the complement of an erosion of the complement.
+template <int NS>
+__global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
+                                                    int w, int h, int words, int strips, int strip_rows,
+                                                    long long total, int first_is_dilate, int nops, int ky, int ay,
+                                                    u32 value, const int32_t* __restrict__ value_dev)
+{
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const int below = ky - 1 - ay;  // rows a window reaches below its output row
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
+        const int j = (int)(c % words);
+        long long t = c / words;
+        const int sidx = (int)(t % strips), b = (int)(t / strips);
+        const int r0 = sidx * strip_rows, r1 = min(r0 + strip_rows, h);
+        const u32* col = bits + (size_t)b * bsw + j;
+        const int rem = w - 32 * j;
+        const u32 wmask = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+        const u32 val = value_dev ? (u32)value_dev[b] : value;
+        const bool dil0 = first_is_dilate != 0;
+        u32 d1[NS], d2[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            d1[i] = ((ky >> i) & 1) ? 0xffffffffu : 0u;  // "no row seen yet"
+            d2[i] = d1[i];
+        }
+        // stage-1 value for row c1 is known once input row c1 + below has been read; stage-2
+        // (if any) for row r once stage-1 row r + below is known.
+        const int lag1 = below, lag2 = nops == 2 ? below : 0;
+        const int y_first = r0 - nops * ay, y_last = r1 - 1 + lag1 + lag2;
+        u32 nxt = 0;
+        if (y_first >= 0 && y_first < h) nxt = col[(size_t)y_first * bpw];
+        for (int y = y_first; y <= y_last; y++) {
+            const u32 raw = nxt;
+            const int yn = y + 1;
+            if (yn >= 0 && yn < h && yn <= y_last) nxt = col[(size_t)yn * bpw];
+            // stage 1 input: image row, or the stage's identity outside the image
+            // (erode: ones; dilate, run as erosion of the complement: also ones)
+            u32 in1 = 0xffffffffu;
+            if (y >= 0 && y < h) in1 = ((dil0 ? ~raw : raw) & wmask) | ~wmask;
+            u32 full1 = run_update<NS>(d1, in1, ky);
+            const int c1 = y - lag1;
+            if (c1 < r0 - (nops == 2 ? ay : 0)) continue;
+            u32 s1 = dil0 ? ~full1 : full1;  // stage-1 result for row c1
+            u32 out;
+            int r;
+            if (nops == 1) {
+                out = s1;
+                r = c1;
+            } else {
+                // stage 2 runs the opposite operation on the stage-1 rows; outside the image
+                // its input is its own identity
+                const bool dil1 = !dil0;
+                u32 in2;
+                if (c1 >= 0 && c1 < h) in2 = ((dil1 ? ~s1 : s1) & wmask) | ~wmask;
+                else in2 = 0xffffffffu;
+                u32 full2 = run_update<NS>(d2, in2, ky);
+                out = dil1 ? ~full2 : full2;
+                r = c1 - lag2;
+            }
+            if (r < r0 || r >= r1) continue;
+            u8* o = dst.row(b, r) + (size_t)j * 32;
+            out &= wmask;
+            expand16(out & 0xffffu, val, o);
+            if (rem > 16) expand16(out >> 16, val, o + 16);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ general 8-bit
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -356,6 +552,36 @@ int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h,
 int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, int h, int batch, int first_is_dilate,
                     int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st)
 {
+    static int fast = -1;  // IPA_BITMORPH_FAST=0 forces the LDS tile kernel
+    if (fast < 0) {
+        const char* e = getenv("IPA_BITMORPH_FAST");
+        fast = e ? atoi(e) : 1;
+    }
+    if (fast && ky == 1 && kx > 1 && nops * ax <= 32 && nops * (kx - 1 - ax) <= 32) {
+        const int cpr = cdiv(w, 16);
+        const long long total = (long long)cpr * h * batch;
+        hipLaunchKernelGGL(k_bitmorph_h3, dim3(stream_grid(total, 256)), dim3(256), 0, st, bits, bpw, bsw, dst, w, h, cpr,
+                           total, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value, value_dev);
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
+    if (fast && kx == 1 && ky > 1 && ky < 256) {
+        const int words = cdiv(w, 32);
+        int strip_rows = 128;
+        // keep at least ~64k lanes in flight for single images
+        while (strip_rows > 16 && (long long)words * cdiv(h, strip_rows) * batch < 65536) strip_rows /= 2;
+        const int strips = cdiv(h, strip_rows);
+        const long long total = (long long)words * strips * batch;
+        const dim3 grid(stream_grid(total, 256)), block(256);
+        if (ky < 32)
+            hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, 0, st, bits, bpw, bsw, dst, w, h, words, strips, strip_rows,
+                               total, first_is_dilate, nops, ky, ay, (u32)value, value_dev);
+        else
+            hipLaunchKernelGGL(k_bitmorph_v<8>, grid, block, 0, st, bits, bpw, bsw, dst, w, h, words, strips, strip_rows,
+                               total, first_is_dilate, nops, ky, ay, (u32)value, value_dev);
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
     BitMorphArgs A;
     A.bits = bits; A.bpw = bpw; A.bsw = bsw; A.dst = dst; A.w = w; A.h = h;
     A.first_is_dilate = first_is_dilate; A.nops = nops;
