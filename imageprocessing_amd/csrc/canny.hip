@@ -16,41 +16,46 @@
 #include "common.hpp"
 
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
 constexpr int TW = 128, TH = 32;
-constexpr int GW = TW + 8;   // gray row bytes in LDS (4-byte halo each side, 2 used)
-constexpr int GH = TH + 4;
-constexpr int MH = TH + 2;               // gradient rows: tile + 1 ring
-constexpr int DW = 136;                  // dwords per row of the gradient array (16-byte aligned tile start)
+constexpr int GH = TH + 4;     // gray rows in LDS: tile + 2 above / below
+constexpr int GP = 160;        // gray row pitch in bytes: LDS column = x - x0 + 16 (tile body 16-byte aligned)
+constexpr int MH = TH + 2;     // magnitude rows: tile + 1 ring
+constexpr int MP = 136;        // magnitude row pitch in u16: column m <-> x = x0 - 4 + m
+constexpr int MGROUPS = 34;    // groups of 4 magnitudes per row
 constexpr u8 WEAK = 1;
 
 struct CannyWs {
     u8* has_weak;   // per tile: the tile holds WEAK pixels
-    u32* again;     // set when a depth-first walk had to drop work in a multi-region image
+    u32* again;     // set when a tile of another workgroup's region has to be revisited
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ int grad_dx(u32 d) { return (int)(d << 16) >> 16; }
-__device__ __forceinline__ int grad_dy(u32 d) { return (int)d >> 16; }
-__device__ __forceinline__ int grad_mag(u32 d) { return abs(grad_dx(d)) + abs(grad_dy(d)); }
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 as_s2(u32 v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ u32 as_u32(s2 v) { return __builtin_bit_cast(u32, v); }
+// two bytes of the 8-byte value {hi, lo} as two zero-extended 16-bit lanes (a -> low lane)
+#define PAIR_SEL(a, b) ((0x0cu << 24) | ((u32)(b) << 16) | (0x0cu << 8) | (u32)(a))
 
 // LDS layout (one 128x32 tile):
-//   g[36][136]  gray bytes, image (y0-2+r, x0-4+c), borders replicated
-//   D[34][136]  Sobel gradients packed (dx & 0xffff) | (dy << 16); entry (r, cc) is image
-//               (y0-1+r, x0-4+cc); zero outside the image so the magnitude there is 0
-//   M[32][128]  output codes 0 / WEAK / 255
-//   Q[4096]     tile-local coordinates of pixels whose magnitude exceeds the low threshold
-// Phases: load gray -> Sobel (4 pixels per lane) -> threshold scan (16 pixels per lane,
-// candidates queued) -> direction test + neighbour compare for queued pixels only ->
-// store codes.  Only ~3 % of the pixels of a diagram are candidates, so the branchy
-// non-maximum test runs on a compacted list with all lanes busy.
+//   g[36][160]   gray bytes, image (y0-2+r, x0-16+c), borders replicated
+//   mag[34][136] |dx|+|dy| as u16, image (y0-1+r, x0-4+m), zero outside the image
+//   M[32][128]   output codes 0 / WEAK / 255
+//   Q[4096]      tile-local coordinates of pixels whose magnitude exceeds the low threshold
+// Phases: load gray (16-byte loads) -> Sobel with packed 16-bit arithmetic, two pixels
+// per instruction, four per lane, magnitudes to LDS and candidates to the queue ->
+// direction test + neighbour compare for queued pixels only -> store codes.  Only ~3 %
+// of the pixels of a diagram are candidates, so the branchy non-maximum test runs on a
+// compacted list with all lanes busy.
 __global__ __launch_bounds__(256) void k_canny_nms(Plane src, Plane dst, int w, int h, int tiles_x, int tiles_y,
                                                    int low, int high, CannyWs W)
 {
-    __shared__ __align__(16) u8 g[GH][GW];
-    __shared__ __align__(16) u32 D[MH][DW];
+    __shared__ __align__(16) u8 g[GH][GP];
+    __shared__ __align__(16) u16 mag[MH][MP];
     __shared__ __align__(16) u8 M[TH][TW];
     __shared__ u16 Q[TH * TW];
     __shared__ u32 s_qn;
@@ -62,19 +67,33 @@ __global__ __launch_bounds__(256) void k_canny_nms(Plane src, Plane dst, int w, 
     const int ty = t2 % tiles_y, b = t2 / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
 
-    for (int e = tid; e < GH * (GW / 4); e += 256) {
-        int r = e / (GW / 4), cd = e - r * (GW / 4);
-        int gy = clampi(y0 - 2 + r, 0, h - 1);
-        int gx = x0 - 4 + cd * 4;
+    // ---- gray tile: per row 8 x 16 bytes of body + one dword of halo on each side
+    for (int e = tid; e < GH * 10; e += 256) {
+        const int r = e / 10, k = e - r * 10;
+        const int gy = clampi(y0 - 2 + r, 0, h - 1);
         const u8* row = src.row(b, gy);
-        u32 v;
-        if (gx >= 0 && gx + 4 <= w) {
-            v = *(const u32*)(row + gx);
+        if (k < 8) {
+            const int gx = x0 + 16 * k;
+            uint4 v;
+            if (gx + 16 <= w) {
+                v = *(const uint4*)(row + gx);
+            } else {
+                u32 d[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 16; j++) d[j >> 2] |= (u32)row[clampi(gx + j, 0, w - 1)] << (8 * (j & 3));
+                v = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            *(uint4*)&g[r][16 + 16 * k] = v;
         } else {
-            v = 0;
-            for (int j = 0; j < 4; j++) v |= (u32)row[clampi(gx + j, 0, w - 1)] << (8 * j);
+            const int gx = k == 8 ? x0 - 4 : x0 + TW;
+            u32 v;
+            if (gx >= 0 && gx + 4 <= w) {
+                v = *(const u32*)(row + gx);
+            } else {
+                v = 0;
+                for (int j = 0; j < 4; j++) v |= (u32)row[clampi(gx + j, 0, w - 1)] << (8 * j);
+            }
+            *(u32*)&g[r][k == 8 ? 12 : 16 + TW] = v;
         }
-        *(u32*)&g[r][cd * 4] = v;
     }
     ((uint4*)&M[0][0])[tid] = make_uint4(0, 0, 0, 0);
     if (tid == 0) {
@@ -83,93 +102,99 @@ __global__ __launch_bounds__(256) void k_canny_nms(Plane src, Plane dst, int w, 
     }
     __syncthreads();
 
-    // Sobel, vertical pass first: vs = top + 2 mid + bot, vd = bot - top per column, then
-    // dx = vs[x+1] - vs[x-1], dy = vd[x-1] + 2 vd[x] + vd[x+1].  One lane = 4 pixels:
-    // gradient columns cc = 4q + 3 .. 4q + 6 need gray bytes 4q + 2 .. 4q + 7.
-    for (int e = tid; e < MH * 33; e += 256) {
-        const int r = e / 33, q = e - r * 33;
-        const u32* g0 = (const u32*)&g[r][4 * q];
-        const u32* g1 = (const u32*)&g[r + 1][4 * q];
-        const u32* g2 = (const u32*)&g[r + 2][4 * q];
-        const uint2 t = make_uint2(g0[0], g0[1]);
-        const uint2 m = make_uint2(g1[0], g1[1]);
-        const uint2 bt = make_uint2(g2[0], g2[1]);
-        int vs[6], vd[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int k = i + 2;  // byte index within the 8 loaded bytes
-            const u32 tw = k < 4 ? t.x : t.y, mw = k < 4 ? m.x : m.y, bw = k < 4 ? bt.x : bt.y;
-            const int tb = (tw >> (8 * (k & 3))) & 0xff, mb = (mw >> (8 * (k & 3))) & 0xff,
-                      bb = (bw >> (8 * (k & 3))) & 0xff;
-            vs[i] = tb + 2 * mb + bb;
-            vd[i] = bb - tb;
+    // ---- Sobel + magnitude, 4 pixels (two 16-bit pairs) per lane and step.
+    // Group q of magnitude row r covers m = 4q .. 4q+3, i.e. x = x0-4+4q ..; it needs the
+    // gray columns x-1 .. x+4 = LDS bytes 4q+11 .. 4q+16 = dwords q+2 (byte 3), q+3, q+4 (byte 0).
+    // vs = top + 2 mid + bot and vd = bot - top are formed for the column pairs
+    // A = (x-1, x), B = (x+1, x+2), C = (x+3, x+4); then
+    //   dx(0,1) = vs_B - vs_A            dx(2,3) = vs_C - vs_B
+    //   dy(0,1) = vd_A + 2 vd(x, x+1) + vd_B   with (x, x+1) = the lanes between A and B, etc.
+    const bool border_tile = x0 == 0 || y0 == 0 || x0 + TW + 1 > w || y0 + TH + 1 > h;
+    for (int e = tid; e < MH * MGROUPS; e += 256) {
+        const int r = e / MGROUPS, q = e - r * MGROUPS;
+        s2 vs[3], vd[3];
+        {
+            const u32* gt = (const u32*)&g[r][0] + q + 2;
+            const u32* gm = (const u32*)&g[r + 1][0] + q + 2;
+            const u32* gb = (const u32*)&g[r + 2][0] + q + 2;
+            const u32 t0 = gt[0], t1 = gt[1], t2 = gt[2];
+            const u32 m0 = gm[0], m1 = gm[1], m2 = gm[2];
+            const u32 b0 = gb[0], b1 = gb[1], b2 = gb[2];
+            // pair A: byte 3 of dword 0, byte 0 of dword 1; B: bytes 1, 2 of dword 1; C: byte 3 of dword 1, byte 0 of dword 2
+            const s2 tA = as_s2(__builtin_amdgcn_perm(t1, t0, PAIR_SEL(3, 4))), tB = as_s2(__builtin_amdgcn_perm(t1, t1, PAIR_SEL(1, 2))),
+                     tC = as_s2(__builtin_amdgcn_perm(t2, t1, PAIR_SEL(3, 4)));
+            const s2 mA = as_s2(__builtin_amdgcn_perm(m1, m0, PAIR_SEL(3, 4))), mB = as_s2(__builtin_amdgcn_perm(m1, m1, PAIR_SEL(1, 2))),
+                     mC = as_s2(__builtin_amdgcn_perm(m2, m1, PAIR_SEL(3, 4)));
+            const s2 bA = as_s2(__builtin_amdgcn_perm(b1, b0, PAIR_SEL(3, 4))), bB = as_s2(__builtin_amdgcn_perm(b1, b1, PAIR_SEL(1, 2))),
+                     bC = as_s2(__builtin_amdgcn_perm(b2, b1, PAIR_SEL(3, 4)));
+            vs[0] = tA + mA + mA + bA; vs[1] = tB + mB + mB + bB; vs[2] = tC + mC + mC + bC;
+            vd[0] = bA - tA; vd[1] = bB - tB; vd[2] = bC - tC;
         }
-        const int iy = y0 - 1 + r;
-        const bool row_in = iy >= 0 && iy < h;
-        u32 o[4];
+        const s2 dx01 = vs[1] - vs[0], dx23 = vs[2] - vs[1];
+        // the pairs that straddle A|B and B|C
+        const s2 vdAB = as_s2(__builtin_amdgcn_alignbit(as_u32(vd[1]), as_u32(vd[0]), 16));
+        const s2 vdBC = as_s2(__builtin_amdgcn_alignbit(as_u32(vd[2]), as_u32(vd[1]), 16));
+        const s2 dy01 = vd[0] + vdAB + vdAB + vd[1], dy23 = vd[1] + vdBC + vdBC + vd[2];
+        s2 m01 = __builtin_elementwise_abs(dx01) + __builtin_elementwise_abs(dy01);
+        s2 m23 = __builtin_elementwise_abs(dx23) + __builtin_elementwise_abs(dy23);
+        u32 mm[2] = {as_u32(m01), as_u32(m23)};
+        const int iy = y0 - 1 + r, ix = x0 - 4 + 4 * q;
+        if (border_tile) {
+            // magnitude outside the image is 0
+            const bool row_in = iy >= 0 && iy < h;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int dx = vs[j + 2] - vs[j];
-            const int dy = vd[j] + 2 * vd[j + 1] + vd[j + 2];
-            const int ix = x0 - 4 + 4 * q + 3 + j;
-            const bool in = row_in && ix >= 0 && ix < w;
-            o[j] = in ? (((u32)dx & 0xffffu) | ((u32)dy << 16)) : 0u;
+            for (int j = 0; j < 4; j++) {
+                const bool in = row_in && ix + j >= 0 && ix + j < w;
+                if (!in) mm[j >> 1] &= (j & 1) ? 0x0000ffffu : 0xffff0000u;
+            }
         }
-        // cc = 4q + 3 + j: not 16-byte aligned, four dword stores
-        u32* drow = &D[r][4 * q + 3];
-        drow[0] = o[0]; drow[1] = o[1]; drow[2] = o[2]; drow[3] = o[3];
+        *(uint2*)&mag[r][4 * q] = make_uint2(mm[0], mm[1]);
+        // candidates: tile pixels (rows 1..32, groups 1..32) above the low threshold
+        if (r >= 1 && r <= TH && q >= 1 && q <= 32) {
+            const int lr = r - 1, lc = 4 * q - 4;
+            u32 cand = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int mv = (int)((mm[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                if (mv > low && iy < h && ix + j < w) cand |= 1u << j;
+            }
+            if (cand) {
+                u32 pos = atomicAdd(&s_qn, (u32)__popc(cand));
+                while (cand) {
+                    const int j = __ffs(cand) - 1;
+                    cand &= cand - 1;
+                    Q[pos++] = (u16)((lr << 7) | (lc + j));
+                }
+            }
+        }
     }
     __syncthreads();
 
-    // threshold scan: lane = 16 consecutive pixels of one tile row
-    const int lr = tid >> 3, lc0 = (tid & 7) * 16;
-    {
-        const int iy = y0 + lr;
-        u32 cand = 0;
-        if (iy < h) {
-            const uint4* dp = (const uint4*)&D[lr + 1][lc0 + 4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint4 v = dp[k];
-                const u32 d4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (grad_mag(d4[j]) > low && x0 + lc0 + 4 * k + j < w) cand |= 1u << (4 * k + j);
-            }
-        }
-        if (cand) {
-            u32 pos = atomicAdd(&s_qn, (u32)__popc(cand));
-            while (cand) {
-                const int i = __ffs(cand) - 1;
-                cand &= cand - 1;
-                Q[pos++] = (u16)((lr << 7) | (lc0 + i));
-            }
-        }
-    }
-    __syncthreads();
-
-    // non-maximum suppression on the queued pixels
+    // ---- non-maximum suppression on the queued pixels
     const u32 qn = s_qn;
     bool weak = false;
     for (u32 i = tid; i < qn; i += 256) {
         const int e = Q[i];
         const int r = e >> 7, c = e & 127;
-        const u32* ctr = &D[r + 1][c + 4];
-        const u32 d = ctr[0];
-        const int dx = grad_dx(d), dy = grad_dy(d);
-        const int m = abs(dx) + abs(dy);
+        const u8* p0 = &g[r + 1][c + 15];  // row above, column x-1
+        const u8* p1 = p0 + GP;
+        const u8* p2 = p1 + GP;
+        const int dx = (p0[2] - p0[0]) + 2 * (p1[2] - p1[0]) + (p2[2] - p2[0]);
+        const int dy = (p2[0] - p0[0]) + 2 * (p2[1] - p0[1]) + (p2[2] - p0[2]);
+        const u16* ctr = &mag[r + 1][c + 4];
+        const int m = ctr[0];
         const int ax = abs(dx), ay = abs(dy) << 15;
         const int tg22x = ax * 13573;
         bool is_max;
         if (ay < tg22x) {
-            is_max = m > grad_mag(ctr[-1]) && m >= grad_mag(ctr[1]);
+            is_max = m > ctr[-1] && m >= ctr[1];
         } else {
             const int tg67x = tg22x + (ax << 16);
             if (ay > tg67x) {
-                is_max = m > grad_mag(ctr[-DW]) && m >= grad_mag(ctr[DW]);
+                is_max = m > ctr[-MP] && m >= ctr[MP];
             } else {
                 const int s = ((dx ^ dy) < 0) ? -1 : 1;
-                is_max = m > grad_mag(ctr[-DW - s]) && m > grad_mag(ctr[DW + s]);
+                is_max = m > ctr[-MP - s] && m > ctr[MP + s];
             }
         }
         if (is_max) {
@@ -182,10 +207,145 @@ __global__ __launch_bounds__(256) void k_canny_nms(Plane src, Plane dst, int w, 
     __syncthreads();
 
     {
+        const int lr = tid >> 3, lc0 = (tid & 7) * 16;
         const int iy = y0 + lr, ix0 = x0 + lc0;
         if (iy < h && ix0 < w) *(uint4*)(dst.row(b, iy) + ix0) = ((const uint4*)&M[0][0])[tid];
     }
     if (tid == 0) W.has_weak[blockIdx.x] = s_weak ? 1 : 0;
+}
+
+// ---- streaming variant: no LDS, no barriers ---------------------------------------
+// One wave walks a 256-pixel-wide strip of the image downwards, one row per step, lane =
+// 4 adjacent pixels.  Everything lives in registers: the last three gray rows (as 16-bit
+// pairs), the last three magnitude rows and the gradients of the middle one.  Column
+// neighbours come from the adjacent lanes by shuffles; the outermost lanes only feed their
+// neighbours (strips overlap by 8 pixels), so a strip yields 248 columns.  Rows are read
+// and written as contiguous 256-byte segments, and neighbouring strips advance together,
+// which keeps the HBM access pattern row-sequential.
+constexpr int ST_ROWS = 64;
+constexpr int ST_COLS = 248;
+
+struct MagRow {
+    u32 m01, m23;  // magnitudes of the lane's 4 pixels (16-bit pairs)
+    u32 mL, mR;    // magnitude just left of pixel 0 / just right of pixel 3
+};
+
+__device__ __forceinline__ u32 stream_load_gray(const Plane& src, int b, int yy, int x, int w, int h)
+{
+    const u8* row = src.row(b, clampi(yy, 0, h - 1));
+    if (x >= 0 && x + 4 <= w) return *(const u32*)(row + x);
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (u32)row[clampi(x + j, 0, w - 1)] << (8 * j);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
+                                                      long long nwaves, int low, int high, int tiles_x, int tiles_y,
+                                                      CannyWs W)
+{
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_id >= nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const int sx = (int)(wave_id % strips_x);
+    long long t = wave_id / strips_x;
+    const int band = (int)(t % bands), b = (int)(t / bands);
+    const int x = sx * ST_COLS - 4 + 4 * lane;
+    const int y0 = band * ST_ROWS, y1 = min(y0 + ST_ROWS, h);
+    // magnitude is 0 outside the image
+    const u32 cm01 = ((x >= 0 && x < w) ? 0x0000ffffu : 0u) | ((x + 1 >= 0 && x + 1 < w) ? 0xffff0000u : 0u);
+    const u32 cm23 = ((x + 2 >= 0 && x + 2 < w) ? 0x0000ffffu : 0u) | ((x + 3 >= 0 && x + 3 < w) ? 0xffff0000u : 0u);
+    const bool writer = lane >= 1 && lane <= 62 && x < w;
+
+    // gray rows yy-2 (a), yy-1 (bq) as 16-bit pairs (columns 0,1 and 2,3)
+    s2 a0, a1, bq0, bq1;
+    {
+        u32 g = stream_load_gray(src, b, y0 - 2, x, w, h);
+        a0 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(0, 1)));
+        a1 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(2, 3)));
+        g = stream_load_gray(src, b, y0 - 1, x, w, h);
+        bq0 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(0, 1)));
+        bq1 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(2, 3)));
+    }
+    MagRow mp = {0, 0, 0, 0}, mc = {0, 0, 0, 0};  // magnitude rows yy-3, yy-2 (set as they appear)
+    u32 dxc01 = 0, dxc23 = 0, dyc01 = 0, dyc23 = 0;  // gradients of row yy-2
+    u32 gnext = stream_load_gray(src, b, y0, x, w, h);
+    for (int yy = y0; yy <= y1 + 1; yy++) {
+        const u32 g = gnext;
+        if (yy + 1 <= y1 + 1) gnext = stream_load_gray(src, b, yy + 1, x, w, h);
+        const s2 c0 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(0, 1))), c1 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(2, 3)));
+        // ---- gradients and magnitude of row yy-1 (gray rows yy-2, yy-1, yy)
+        const s2 vs0 = a0 + bq0 + bq0 + c0, vs1 = a1 + bq1 + bq1 + c1;
+        const s2 vd0 = c0 - a0, vd1 = c1 - a1;
+        const u32 vsL = __shfl_up(as_u32(vs1), 1), vsR = __shfl_down(as_u32(vs0), 1);
+        const u32 vdL = __shfl_up(as_u32(vd1), 1), vdR = __shfl_down(as_u32(vd0), 1);
+        const s2 vsm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vs0), vsL, 16));          // columns -1, 0
+        const s2 vs12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vs1), as_u32(vs0), 16));   // columns 1, 2
+        const s2 vs34 = as_s2(__builtin_amdgcn_alignbit(vsR, as_u32(vs1), 16));           // columns 3, 4
+        const s2 vdm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd0), vdL, 16));
+        const s2 vd12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd1), as_u32(vd0), 16));
+        const s2 vd34 = as_s2(__builtin_amdgcn_alignbit(vdR, as_u32(vd1), 16));
+        const s2 dx01 = vs12 - vsm10, dx23 = vs34 - vs12;
+        const s2 dy01 = vdm10 + vd0 + vd0 + vd12, dy23 = vd12 + vd1 + vd1 + vd34;
+        MagRow mn;
+        {
+            const bool row_in = yy - 1 >= 0 && yy - 1 < h;
+            const u32 m01 = as_u32(__builtin_elementwise_abs(dx01) + __builtin_elementwise_abs(dy01));
+            const u32 m23 = as_u32(__builtin_elementwise_abs(dx23) + __builtin_elementwise_abs(dy23));
+            mn.m01 = row_in ? (m01 & cm01) : 0u;
+            mn.m23 = row_in ? (m23 & cm23) : 0u;
+            mn.mL = __shfl_up(mn.m23, 1) >> 16;
+            mn.mR = __shfl_down(mn.m01, 1) & 0xffffu;
+        }
+        // ---- non-maximum suppression of row yy-2 (magnitude rows yy-3 = mp, yy-2 = mc, yy-1 = mn)
+        const int ry = yy - 2;
+        if (ry >= y0 && ry < y1) {
+            const int cm[4] = {(int)(mc.m01 & 0xffffu), (int)(mc.m01 >> 16), (int)(mc.m23 & 0xffffu), (int)(mc.m23 >> 16)};
+            u32 cand = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) cand |= (cm[j] > low ? 1u : 0u) << j;
+            u32 codes = 0;
+            if (__any(cand != 0)) {
+                const int vP[6] = {(int)mp.mL, (int)(mp.m01 & 0xffffu), (int)(mp.m01 >> 16), (int)(mp.m23 & 0xffffu), (int)(mp.m23 >> 16), (int)mp.mR};
+                const int vC[6] = {(int)mc.mL, cm[0], cm[1], cm[2], cm[3], (int)mc.mR};
+                const int vN[6] = {(int)mn.mL, (int)(mn.m01 & 0xffffu), (int)(mn.m01 >> 16), (int)(mn.m23 & 0xffffu), (int)(mn.m23 >> 16), (int)mn.mR};
+                const int dxs[4] = {(int)(dxc01 << 16) >> 16, (int)dxc01 >> 16, (int)(dxc23 << 16) >> 16, (int)dxc23 >> 16};
+                const int dys[4] = {(int)(dyc01 << 16) >> 16, (int)dyc01 >> 16, (int)(dyc23 << 16) >> 16, (int)dyc23 >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!((cand >> j) & 1u)) continue;
+                    const int m = vC[j + 1], dx = dxs[j], dy = dys[j];
+                    const int ax = abs(dx), ay = abs(dy) << 15;
+                    const int tg22x = ax * 13573;
+                    bool is_max;
+                    if (ay < tg22x) {
+                        is_max = m > vC[j] && m >= vC[j + 2];
+                    } else {
+                        const int tg67x = tg22x + (ax << 16);
+                        if (ay > tg67x) {
+                            is_max = m > vP[j + 1] && m >= vN[j + 1];
+                        } else {
+                            const bool neg = (dx ^ dy) < 0;  // s = -1
+                            const int pv = neg ? vP[j + 2] : vP[j];
+                            const int nv = neg ? vN[j] : vN[j + 2];
+                            is_max = m > pv && m > nv;
+                        }
+                    }
+                    if (is_max) codes |= (m > high ? 255u : (u32)WEAK) << (8 * j);
+                }
+            }
+            if (writer) {
+                *(u32*)(dst.row(b, ry) + x) = codes;
+                // any WEAK byte (value 1, top bit clear) flags the 128x32 tile for the hysteresis
+                if (codes & ~(codes >> 7) & 0x01010101u)
+                    W.has_weak[((size_t)b * tiles_y + ry / TH) * tiles_x + x / TW] = 1;
+            }
+        }
+        // ---- roll the window
+        a0 = bq0; a1 = bq1; bq0 = c0; bq1 = c1;
+        mp = mc; mc = mn;
+        dxc01 = as_u32(dx01); dxc23 = as_u32(dx23); dyc01 = as_u32(dy01); dyc23 = as_u32(dy23);
+    }
 }
 
 constexpr int HT_THREADS = 512;      // 8 waves per workgroup
@@ -428,10 +588,24 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     CannyWs W;
     W.has_weak = (u8*)ws;
     W.again = (u32*)((u8*)ws + align_up(ntiles, 256));
+    static int mode = -1;  // IPA_CANNY_MODE: 1 = streaming register kernel (default), 0 = LDS tile kernel
+    if (mode < 0) {
+        const char* e = getenv("IPA_CANNY_MODE");
+        mode = e ? atoi(e) : 1;
+    }
     {
         ProfScope ps(PROF_CANNY_NMS, st);
-        hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)ntiles), dim3(256), 0, st, src, dst, w, h, tiles_x, tiles_y, low,
-                           high, W);
+        if (mode == 1) {
+            IPA_HIP(hipMemsetAsync(W.has_weak, 0, ntiles, st));
+            const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
+            const long long nwaves = (long long)strips_x * bands * batch;
+            IPA_REQUIRE(nwaves / 4 + 1 < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
+            hipLaunchKernelGGL(k_canny_stream, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h, strips_x,
+                               bands, nwaves, low, high, tiles_x, tiles_y, W);
+        } else {
+            hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)ntiles), dim3(256), 0, st, src, dst, w, h, tiles_x, tiles_y, low,
+                               high, W);
+        }
         IPA_LAUNCH_CHECK();
     }
     ProfScope ps(PROF_HYSTERESIS, st);
