@@ -3,6 +3,7 @@
 #include "common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -192,10 +193,22 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     }
     double lo = canny_lo, hi = canny_hi;
     if (lo > hi) { double t = lo; lo = hi; hi = t; }
-    rc = run_canny(csrc, E, width, height, batch, (int)floor(lo), (int)floor(hi), canny_ws, L.canny_bytes, st);
+    // with a Hough stage behind it, Canny also emits the list of edge pixels
+    PointSink sink = {nullptr, 0, 0, nullptr};
+    static int fused = -1;  // IPA_FUSED_POINTS=1: the Canny kernels emit the edge-pixel list themselves (default: a
+                            // separate compaction pass over the edge plane, which measures faster end to end)
+    if (fused < 0) {
+        const char* e = getenv("IPA_FUSED_POINTS");
+        fused = e ? atoi(e) : 0;
+    }
+    if (accum && fused) {
+        sink = hough_point_sink(width, height, max_points, point_counts, hough_ws);
+        IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+    }
+    rc = run_canny(csrc, E, width, height, batch, (int)floor(lo), (int)floor(hi), canny_ws, L.canny_bytes, sink, st);
     if (rc) return rc;
     if (accum)
         rc = run_hough_accum(E, width, height, batch, 1.0, M_PI / 180, accum, accum_stride, max_points, point_counts,
-                             hough_ws, L.hough_bytes, st);
+                             hough_ws, L.hough_bytes, fused != 0, st);
     return rc;
 }

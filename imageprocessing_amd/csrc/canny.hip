@@ -240,13 +240,31 @@ __device__ __forceinline__ u32 stream_load_gray(const Plane& src, int b, int yy,
     return v;
 }
 
+template <bool EMIT>
 __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
                                                       long long nwaves, int low, int high, int tiles_x, int tiles_y,
-                                                      CannyWs W)
+                                                      CannyWs W, PointSink sink)
 {
+    __shared__ u32 s_pts[EMIT ? 4 : 1][EMIT ? 256 : 1];  // per wave: edge pixels waiting to be appended
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wave_id >= nwaves) return;
     const int lane = threadIdx.x & 63;
+    u32* pbuf = s_pts[EMIT ? (threadIdx.x >> 6) : 0];
+    u32 fill = 0;  // wave-uniform
+    // append the buffered points to the image's list: one atomic per flush, coalesced stores
+    auto flush = [&](int bimg) {
+        if (!EMIT || fill == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u32 base = 0;
+        if (lane == 0) base = (u32)atomicAdd(&sink.counts[bimg], (int32_t)fill);
+        base = __shfl(base, 0);
+        u32* out = sink.pts + (size_t)bimg * sink.stride;
+        for (u32 i = lane; i < fill; i += 64)
+            if (base + i < sink.cap) out[base + i] = pbuf[i];
+        __builtin_amdgcn_wave_barrier();
+        fill = 0;
+    };
     const int sx = (int)(wave_id % strips_x);
     long long t = wave_id / strips_x;
     const int band = (int)(t % bands), b = (int)(t / bands);
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     MagRow mp = {0, 0, 0, 0}, mc = {0, 0, 0, 0};  // magnitude rows yy-3, yy-2 (set as they appear)
     u32 dxc01 = 0, dxc23 = 0, dyc01 = 0, dyc23 = 0;  // gradients of row yy-2
     u32 gnext = stream_load_gray(src, b, y0, x, w, h);
+#pragma unroll 6
     for (int yy = y0; yy <= y1 + 1; yy++) {
         const u32 g = gnext;
         if (yy + 1 <= y1 + 1) gnext = stream_load_gray(src, b, yy + 1, x, w, h);
@@ -340,12 +359,32 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
                 if (codes & ~(codes >> 7) & 0x01010101u)
                     W.has_weak[((size_t)b * tiles_y + ry / TH) * tiles_x + x / TW] = 1;
             }
+            if (EMIT) {
+                // strong pixels (255) of this row -> the wave's buffer, in lane order per pixel column
+                const u32 st4 = writer ? ((codes >> 7) & 0x01010101u) : 0u;
+                if (__any(st4 != 0)) {
+                    // in x order: pixels of lower lanes first, then this lane's own from left to right
+                    const unsigned long long m0 = __ballot(st4 & 0x1u), m1 = __ballot(st4 & 0x100u),
+                                             m2 = __ballot(st4 & 0x10000u), m3 = __ballot(st4 & 0x1000000u);
+                    const u32 total = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                    if (fill + total > 256) flush(b);
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    u32 pos = fill + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+                    const u32 xy = ((u32)ry << 16) | (u32)x;
+                    if (st4 & 0x1u) pbuf[pos++] = xy;
+                    if (st4 & 0x100u) pbuf[pos++] = xy + 1;
+                    if (st4 & 0x10000u) pbuf[pos++] = xy + 2;
+                    if (st4 & 0x1000000u) pbuf[pos++] = xy + 3;
+                    fill += total;
+                }
+            }
         }
         // ---- roll the window
         a0 = bq0; a1 = bq1; bq0 = c0; bq1 = c1;
         mp = mc; mc = mn;
         dxc01 = as_u32(dx01); dxc23 = as_u32(dx23); dyc01 = as_u32(dy01); dyc23 = as_u32(dy23);
     }
+    flush(b);
 }
 
 constexpr int HT_THREADS = 512;      // 8 waves per workgroup
@@ -400,7 +439,7 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
 // the stores) and an L1 invalidate, so a round sees everything the previous one wrote.
 __global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
                                                            int rt_x, int rt_y, int regions_x, int regions_y,
-                                                           CannyWs W)
+                                                           CannyWs W, PointSink sink)
 {
     __shared__ u16 s_list[2][HT_MAX_TILES];
     __shared__ u32 s_inq[HT_MAX_TILES / 32];
@@ -500,6 +539,29 @@ __global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int
                     if (nib) atomicOr((u32*)(row + 4 * q), ((nib * 0x00204081u) & 0x01010101u) * 0xffu);
                 }
             }
+            if (sink.pts && __any(prom != 0)) {
+                // promoted pixels join the image's edge-pixel list: one atomic per tile visit
+                const u32 cnt = (u32)__popcll(prom);
+                u32 scan = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const u32 tt = __shfl_up(scan, o);
+                    if (lane >= o) scan += tt;
+                }
+                const u32 total = __shfl(scan, 63);
+                u32 base = 0;
+                if (lane == 63) base = (u32)atomicAdd(&sink.counts[b], (int32_t)total);
+                base = __shfl(base, 63);
+                u32 pos = base + scan - cnt;
+                u32* out = sink.pts + (size_t)b * sink.stride;
+                u64 pm = prom;
+                while (pm) {
+                    const int bit = __ffsll((long long)pm) - 1;
+                    pm &= pm - 1;
+                    if (pos < sink.cap) out[pos] = ((u32)iy << 16) | (u32)(xh + bit);
+                    pos++;
+                }
+            }
             // rim changed -> neighbours with WEAK pixels are due in the next round
             const bool rim = prom && (r == 0 || r == TH - 1 || (hf == 0 && (prom & 1ull)) || (hf == 1 && (prom >> 63)));
             if (__any(rim) && lane < 9 && lane != 4) {
@@ -577,7 +639,7 @@ size_t canny_ws_bytes(int w, int h, int batch)
 // into regions and the stream is synchronised to learn whether a further
 // hysteresis launch is needed.
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
-              hipStream_t st)
+              PointSink sink, hipStream_t st)
 {
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     const long long ntiles_ll = (long long)tiles_x * tiles_y * batch;
@@ -600,9 +662,14 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
             const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;
             IPA_REQUIRE(nwaves / 4 + 1 < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
-            hipLaunchKernelGGL(k_canny_stream, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h, strips_x,
-                               bands, nwaves, low, high, tiles_x, tiles_y, W);
+            if (sink.pts)
+                hipLaunchKernelGGL(k_canny_stream<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h,
+                                   strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
+            else
+                hipLaunchKernelGGL(k_canny_stream<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h,
+                                   strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
         } else {
+            IPA_REQUIRE(!sink.pts, IPA_ERR_ARG, "Canny: the LDS tile kernel cannot emit the edge-pixel list");
             hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)ntiles), dim3(256), 0, st, src, dst, w, h, tiles_x, tiles_y, low,
                                high, W);
         }
@@ -623,7 +690,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     for (int guard = 0; guard < 100000; guard++) {
         if (multi) IPA_HIP(hipMemsetAsync(W.again, 0, 4, st));
         hipLaunchKernelGGL(k_hyst_tiles, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x, tiles_y, rt_x,
-                           rt_y, regions_x, regions_y, W);
+                           rt_y, regions_x, regions_y, W, sink);
         IPA_LAUNCH_CHECK();
         if (!multi) break;
         u32 again;
@@ -665,5 +732,6 @@ IPA_EXPORT int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_str
     double fl = floor(threshold1), fh = floor(threshold2);
     int low = fl < -1 ? -1 : (fl > 1e6 ? 1000000 : (int)fl);
     int high = fh < -1 ? -1 : (fh > 1e6 ? 1000000 : (int)fh);
-    return run_canny(s, d, width, height, batch, low, high, ws, ws_bytes, (hipStream_t)stream);
+    PointSink none = {nullptr, 0, 0, nullptr};
+    return run_canny(s, d, width, height, batch, low, high, ws, ws_bytes, none, (hipStream_t)stream);
 }

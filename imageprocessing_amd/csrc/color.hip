@@ -22,68 +22,66 @@ __device__ __forceinline__ u32 luma(u32 b, u32 g, u32 r) { return (b * 3735u + g
 // of the bit plane.
 template <bool THRESH, bool PACK>
 __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* __restrict__ bits,
-                                                  size_t bpw, size_t bsw, int w, int h, int cpr, long long total,
-                                                  int ithresh, u32 v_above, u32 v_below)
+                                                  size_t bpw, size_t bsw, int w, int h, int cpr, int ithresh,
+                                                  u32 v_above, u32 v_below)
 {
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < total; base += step) {
-        const long long c = base + threadIdx.x;
-        u32 mybits = 0;
-        int cx = 0, y = 0, b = 0;
-        bool live = c < total;
-        if (live) {
-            cx = (int)(c % cpr);
-            long long t = c / cpr;
-            y = (int)(t % h);
-            b = (int)(t / h);
-            live = cx * 16 < w;
+    const int cx = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.z;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * ROWS_PER_LANE;
+    const bool live = cx < cpr && cx * 16 < w;
+    const bool full = cx * 16 + 16 <= w;
+    // all loads of the lane's rows are issued before the first is used
+    uint4 in[ROWS_PER_LANE][3];
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        const int y = y0 + i;
+        if (live && full && y < h) {
+            const uint4* s4 = (const uint4*)(bgr.row(b, y) + (size_t)cx * 48);
+            in[i][0] = s4[0]; in[i][1] = s4[1]; in[i][2] = s4[2];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        const int y = y0 + i;
+        if (y >= h) break;  // uniform per wave: a wave's lanes share ty
+        u32 mybits = 0;
         if (live) {
-            const u8* s = bgr.row(b, y) + (size_t)cx * 48;
             u8* gd = gray.row(b, y) + (size_t)cx * 16;
-            if (cx * 16 + 16 <= w) {
-                u32 d[12];
-                const uint4* s4 = (const uint4*)s;
-                uint4 a0 = s4[0], a1 = s4[1], a2 = s4[2];
-                d[0] = a0.x; d[1] = a0.y; d[2] = a0.z; d[3] = a0.w;
-                d[4] = a1.x; d[5] = a1.y; d[6] = a1.z; d[7] = a1.w;
-                d[8] = a2.x; d[9] = a2.y; d[10] = a2.z; d[11] = a2.w;
+            if (full) {
+                const u32 d[12] = {in[i][0].x, in[i][0].y, in[i][0].z, in[i][0].w, in[i][1].x, in[i][1].y,
+                                   in[i][1].z, in[i][1].w, in[i][2].x, in[i][2].y, in[i][2].z, in[i][2].w};
                 u32 g[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    u32 v = luma(byte_of(d, 3 * i), byte_of(d, 3 * i + 1), byte_of(d, 3 * i + 2));
-                    g[i >> 2] |= v << (8 * (i & 3));
+                for (int k = 0; k < 16; k++) {
+                    u32 v = luma(byte_of(d, 3 * k), byte_of(d, 3 * k + 1), byte_of(d, 3 * k + 2));
+                    g[k >> 2] |= v << (8 * (k & 3));
                     if (THRESH) {
                         bool above = (int)v > ithresh;
-                        t[i >> 2] |= (above ? v_above : v_below) << (8 * (i & 3));
-                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << i;
+                        t[k >> 2] |= (above ? v_above : v_below) << (8 * (k & 3));
+                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << k;
                     }
                 }
                 *(uint4*)gd = make_uint4(g[0], g[1], g[2], g[3]);
                 if (THRESH) *(uint4*)(bin.row(b, y) + (size_t)cx * 16) = make_uint4(t[0], t[1], t[2], t[3]);
             } else {
+                const u8* s = bgr.row(b, y) + (size_t)cx * 48;
                 const int n = w - cx * 16;
                 u8* td = THRESH ? bin.row(b, y) + (size_t)cx * 16 : nullptr;
-                for (int i = 0; i < n; i++) {
-                    u32 v = luma(s[3 * i], s[3 * i + 1], s[3 * i + 2]);
-                    gd[i] = (u8)v;
+                for (int k = 0; k < n; k++) {
+                    u32 v = luma(s[3 * k], s[3 * k + 1], s[3 * k + 2]);
+                    gd[k] = (u8)v;
                     if (THRESH) {
                         bool above = (int)v > ithresh;
-                        td[i] = (u8)(above ? v_above : v_below);
-                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << i;
+                        td[k] = (u8)(above ? v_above : v_below);
+                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << k;
                     }
                 }
             }
         }
         if (PACK) {
-            // all 64 lanes reach this shuffle: the loop bounds are wave-uniform
+            // lanes 2k / 2k+1 hold the two halves of one word of the bit plane (cpr is even)
             u32 other = __shfl_xor(mybits, 1);
-            if (c < total && !(threadIdx.x & 1)) {
-                int cx0 = (int)(c % cpr);
-                long long t = c / cpr;
-                int yy = (int)(t % h), bb = (int)(t / h);
-                bits[(size_t)bb * bsw + (size_t)yy * bpw + (cx0 >> 1)] = mybits | (other << 16);
-            }
+            if (cx < cpr && !(threadIdx.x & 1)) bits[(size_t)b * bsw + (size_t)y * bpw + (cx >> 1)] = mybits | (other << 16);
         }
     }
 }
@@ -281,21 +279,25 @@ int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, siz
 {
     int cpr = cdiv(w, 16);
     cpr += cpr & 1;
-    long long total = (long long)cpr * h * batch;
-    if (total == 0) return IPA_OK;
-    unsigned grid = stream_grid(total, 256);
+    if (cpr == 0 || h == 0 || batch == 0) return IPA_OK;
     u32 va = inv ? 0u : (u32)maxval, vb = inv ? (u32)maxval : 0u;
-    // the bit plane holds "pixel is non-zero in the thresholded plane"
-    if (bin.p && bits)
-        hipLaunchKernelGGL((k_bgr2gray<true, true>), dim3(grid), dim3(256), 0, st, bgr, gray, bin, bits, bpw, bsw, w, h,
-                           cpr, total, ithresh, va, vb);
-    else if (bin.p)
-        hipLaunchKernelGGL((k_bgr2gray<true, false>), dim3(grid), dim3(256), 0, st, bgr, gray, bin, bits, bpw, bsw, w,
-                           h, cpr, total, ithresh, va, vb);
-    else
-        hipLaunchKernelGGL((k_bgr2gray<false, false>), dim3(grid), dim3(256), 0, st, bgr, gray, bin, bits, bpw, bsw, w,
-                           h, cpr, total, ithresh, va, vb);
-    IPA_LAUNCH_CHECK();
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        Plane sb = bgr, gb = gray, tb = bin;
+        sb.p += (size_t)b0 * bgr.stride;
+        gb.p += (size_t)b0 * gray.stride;
+        if (tb.p) tb.p += (size_t)b0 * bin.stride;
+        u32* bb = bits ? bits + (size_t)b0 * bsw : nullptr;
+        const dim3 grid = rows_grid(cpr, h, nb), block = rows_block();
+        // the bit plane holds "pixel is non-zero in the thresholded plane"
+        if (bin.p && bits)
+            hipLaunchKernelGGL((k_bgr2gray<true, true>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb);
+        else if (bin.p)
+            hipLaunchKernelGGL((k_bgr2gray<true, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb);
+        else
+            hipLaunchKernelGGL((k_bgr2gray<false, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb);
+        IPA_LAUNCH_CHECK();
+    }
     return IPA_OK;
 }
 

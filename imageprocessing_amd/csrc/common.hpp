@@ -83,6 +83,13 @@ static inline unsigned stream_grid(long long items, int block)
     return (unsigned)g;
 }
 
+// Decomposition of the streaming kernels: blockDim = (64, 4); thread (tx, ty) of block
+// (bx, by, bz) owns 16-pixel chunk column cx = 64 bx + tx of rows
+// [(4 by + ty) * ROWS_PER_LANE, ... + ROWS_PER_LANE) of image bz.  Only 32-bit index math.
+constexpr int ROWS_PER_LANE = 4;
+static inline dim3 rows_block() { return dim3(64, 4, 1); }
+static inline dim3 rows_grid(int cols, int h, int nb) { return dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(h, 4 * ROWS_PER_LANE), (unsigned)nb); }
+
 // Bump allocator over the caller's workspace.
 struct Arena {
     u8* base;
@@ -136,10 +143,20 @@ int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batc
                          int ax, int ay, hipStream_t st);
 int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, hipStream_t st);
 
+// Per-image lists of edge pixels (y << 16 | x), appended to by the Canny kernels when the
+// Hough transform follows, so that the edge plane is not read a second time.
+struct PointSink {
+    u32* pts;         // image b at pts + b * stride; nullptr = no list wanted
+    size_t stride;    // elements
+    u32 cap;          // entries kept per image (the count keeps counting beyond it)
+    int32_t* counts;  // per image, zeroed by the caller
+};
+
 size_t canny_ws_bytes(int w, int h, int batch);
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
-              hipStream_t st);
+              PointSink sink, hipStream_t st);
 
 size_t hough_ws_bytes(int w, int h, int batch, int max_points);
+PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, void* ws);
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, hipStream_t st);
+                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready, hipStream_t st);

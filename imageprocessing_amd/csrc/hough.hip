@@ -96,6 +96,7 @@ struct VoteArgs {
     int nseg;      // slices of the padded rho axis
     int seg_cols;  // columns (of numrho+2) per slice
     int span_max;  // LDS bins per angle
+    int seg_walk;  // 1: each lane walks a contiguous segment of the point list
 };
 
 __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
@@ -161,13 +162,20 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
     const u32* pts = A.pts + (size_t)b * A.pts_stride;
     const uint4* pts4 = (const uint4*)pts;
     const u32 nfull = npts >> 2;  // whole groups of four points
-    u32 i = tid;
+    // Every lane walks its own contiguous segment of the list, so the 64 lanes of a wave
+    // are always at 64 places spread over the whole image: neighbouring pixels of a line
+    // (equal or adjacent rho for many angles) never vote in the same instruction, which
+    // would serialise on one LDS bank.
+    const u32 seglen = A.seg_walk ? (nfull + VOTE_THREADS - 1) / VOTE_THREADS : 1u;
+    const u32 stride = A.seg_walk ? 1u : (u32)VOTE_THREADS;
+    u32 i = A.seg_walk ? tid * seglen : tid;
+    const u32 iend = A.seg_walk ? min(i + seglen, nfull) : nfull;
     uint4 cur = make_uint4(0, 0, 0, 0);
-    if (i < nfull) cur = pts4[i];
-    while (i < nfull) {
-        const u32 inext = i + VOTE_THREADS;
+    if (i < iend) cur = pts4[i];
+    while (i < iend) {
+        const u32 inext = i + stride;
         uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (inext < nfull) nxt = pts4[inext];
+        if (inext < iend) nxt = pts4[inext];
         const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
         const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
         const f2 y01 = {(float)(cur.x >> 16), (float)(cur.y >> 16)};
@@ -232,6 +240,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
         for (int col = seg_lo + tid; col < seg_hi; col += VOTE_THREADS) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
 }
 
+// Four cells per lane and trip (independent loads); the four neighbours are read only for
+// the few cells above the threshold.
 __global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__ accum, size_t accum_stride,
                                                      int numangle, int numrho, int threshold,
                                                      u64* __restrict__ keys, int capacity,
@@ -240,31 +250,40 @@ __global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__
     const int b = blockIdx.y;
     const int32_t* acc = accum + (size_t)b * accum_stride;
     const int ncols = numrho + 2;
-    const long long cells = (long long)numangle * numrho;
-    const long long step = (long long)gridDim.x * blockDim.x;
+    const int cells = numangle * numrho;
     const int lane = threadIdx.x & 63;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < cells; base += step) {
-        long long i = base + threadIdx.x;
-        bool peak = false;
-        int v = 0;
-        long long idx = 0;
-        if (i < cells) {
-            int n = (int)(i / numrho), r = (int)(i - (long long)n * numrho);
-            idx = (long long)(n + 1) * ncols + r + 1;
-            v = acc[idx];
-            if (v > threshold)
-                peak = v > acc[idx - 1] && v >= acc[idx + 1] && v > acc[idx - ncols] && v >= acc[idx + ncols];
+    const int step = gridDim.x * blockDim.x * 4;
+    for (int base = blockIdx.x * blockDim.x * 4; base < cells; base += step) {
+        int v[4], idx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + k * 256 + threadIdx.x;
+            v[k] = 0;
+            idx[k] = 0;
+            if (i < cells) {
+                const int n = i / numrho, r = i - n * numrho;
+                idx[k] = (n + 1) * ncols + r + 1;
+                v[k] = acc[idx[k]];
+            }
         }
-        unsigned long long m = __ballot(peak);
-        if (m) {
-            int leader = __ffsll((long long)m) - 1;
-            int32_t basepos = 0;
-            if (lane == leader) basepos = atomicAdd(&counts[b], (int32_t)__popcll(m));
-            basepos = __shfl(basepos, leader);
-            if (peak) {
-                int pos = basepos + (int)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < capacity)
-                    keys[(size_t)b * capacity + pos] = ((u64)(u32)v << 32) | (u64)(0xffffffffu - (u32)idx);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bool peak = false;
+            if (v[k] > threshold) {
+                const int id = idx[k];
+                peak = v[k] > acc[id - 1] && v[k] >= acc[id + 1] && v[k] > acc[id - ncols] && v[k] >= acc[id + ncols];
+            }
+            const unsigned long long m = __ballot(peak);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int32_t basepos = 0;
+                if (lane == leader) basepos = atomicAdd(&counts[b], (int32_t)__popcll(m));
+                basepos = __shfl(basepos, leader);
+                if (peak) {
+                    const int pos = basepos + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < capacity)
+                        keys[(size_t)b * capacity + pos] = ((u64)(u32)v[k] << 32) | (u64)(0xffffffffu - (u32)idx[k]);
+                }
             }
         }
     }
@@ -306,8 +325,20 @@ size_t hough_ws_bytes(int w, int h, int batch, int max_points)
     return align_up((size_t)point_cap(w, h, max_points) * 4, 256) * (size_t)batch + 256;
 }
 
+PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, void* ws)
+{
+    PointSink k;
+    k.cap = point_cap(w, h, max_points);
+    k.stride = align_up((size_t)k.cap * 4, 256) / 4;
+    k.pts = (u32*)ws;
+    k.counts = point_counts;
+    return k;
+}
+
+// `points_ready`: the per-image point lists (layout of hough_point_sink) and point_counts were
+// already produced by the Canny kernels; otherwise they are compacted from `src` here.
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, hipStream_t st)
+                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready, hipStream_t st)
 {
     IPA_REQUIRE(w <= 65535 && h <= 65535, IPA_ERR_ARG, "HoughLines: image larger than 65535 pixels on a side");
     int numangle, numrho;
@@ -333,11 +364,12 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             T.c[n] = (float)(cos((double)ang) * irho);
         }
     }
-    IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
-    {
+    if (!points_ready) {
+        IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
         ProfScope ps(PROF_HOUGH_COMPACT, st);
         int cpr = cdiv(w, 16);
-        long long cpi = (long long)cpr * h;
+        IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL, IPA_ERR_ARG, "HoughLines: image too large");
+        int cpi = cpr * h;
         unsigned gx = (unsigned)((cpi + 255) / 256);
         unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
         if (capx < 1) capx = 1;
@@ -380,6 +412,12 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         const char* e = getenv("IPA_VOTE_MODE");
         mode = e ? atoi(e) : 0;
     }
+    static int segw = -1;  // IPA_VOTE_SEGWALK: 1 = per-lane list segments, 0 = interleaved (default)
+    if (segw < 0) {
+        const char* e = getenv("IPA_VOTE_SEGWALK");
+        segw = e ? atoi(e) : 0;
+    }
+    A.seg_walk = segw;
     const bool pack16 = ((long long)w + h) < 65535 && mode == 1;
     const bool check = A.nseg > 1;
     const int span_words = pack16 ? (A.span_max + 1) / 2 : A.span_max;
@@ -454,7 +492,7 @@ IPA_EXPORT int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t s
     IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
                 "HoughLines: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
     return run_hough_accum(s, width, height, batch, rho, theta, accum, accum_stride, max_points, point_counts, ws,
-                           ws_bytes, st);
+                           ws_bytes, false, st);
 }
 
 IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle, int numrho, int batch,
@@ -466,8 +504,9 @@ IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, in
     hipStream_t st = (hipStream_t)stream;
     IPA_HIP(hipMemsetAsync(peak_counts, 0, sizeof(int32_t) * (size_t)batch, st));
     long long cells = (long long)numangle * numrho;
-    unsigned gx = (unsigned)((cells + 255) / 256);
-    unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
+    IPA_REQUIRE((long long)(numangle + 2) * (numrho + 2) < 0x7fffffffLL, IPA_ERR_ARG, "HoughLines: accumulator too large");
+    unsigned gx = (unsigned)((cells + 1023) / 1024);
+    unsigned capx = (unsigned)(16384 / (batch < 16384 ? batch : 16384));
     if (capx < 1) capx = 1;
     if (gx > capx) gx = capx;
     ProfScope ps(PROF_HOUGH_PEAKS, st);

@@ -275,34 +275,42 @@ __device__ __forceinline__ Win3 comb3(Win3 a, Win3 b, bool dil)
 
 // Horizontal erode / dilate / open / close of a bit plane whose whole reach fits in the
 // neighbouring words (nops*ax <= 32 and nops*(kx-1-ax) <= 32: e.g. the 29-pixel line
-// kernel of the parsers).  One lane = 16 output pixels (one 16-byte store); it holds
-// words j-1, j, j+1 of its row in registers and runs the doubling steps there.
+// kernel of the parsers).  One lane = one 32-pixel word of 4 consecutive rows; it holds
+// words j-1, j, j+1 of a row in registers, runs the doubling steps there and stores the
+// 32 result bytes.
 __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
-                                                     int w, int h, int cpr, long long total, int first_is_dilate,
-                                                     int nops, int kx, int ax, int px, u32 value,
-                                                     const int32_t* __restrict__ value_dev)
+                                                     int w, int h, int first_is_dilate, int nops, int kx, int ax,
+                                                     int px, u32 value, const int32_t* __restrict__ value_dev)
 {
-    const long long step = (long long)gridDim.x * blockDim.x;
     const int words = (w + 31) >> 5;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
-        const int cx = (int)(c % cpr);
-        long long t = c / cpr;
-        const int y = (int)(t % h), b = (int)(t / h);
-        const int j = cx >> 1;
-        const u32* row = bits + (size_t)b * bsw + (size_t)y * bpw;
-        // in-image masks of the three words
-        Win3 m;
-        m.a0 = j >= 1 ? 0xffffffffu : 0u;
-        {
-            int rem = w - 32 * j;
-            m.a1 = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-            rem -= 32;
-            m.a2 = rem >= 32 ? 0xffffffffu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.z;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * ROWS_PER_LANE;
+    if (j >= words) return;
+    // in-image masks of the three words
+    Win3 m;
+    m.a0 = j >= 1 ? 0xffffffffu : 0u;
+    int rem = w - 32 * j;
+    m.a1 = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+    m.a2 = rem - 32 >= 32 ? 0xffffffffu : (rem - 32 > 0 ? ((1u << (rem - 32)) - 1u) : 0u);
+    const u32 val = value_dev ? (u32)value_dev[b] : value;
+    Win3 in[ROWS_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        const int y = y0 + i;
+        in[i].a0 = in[i].a1 = in[i].a2 = 0;
+        if (y < h) {
+            const u32* row = bits + (size_t)b * bsw + (size_t)y * bpw;
+            in[i].a0 = j >= 1 ? row[j - 1] : 0u;
+            in[i].a1 = row[j];
+            in[i].a2 = j + 1 < words ? row[j + 1] : 0u;
         }
-        Win3 v;
-        v.a0 = j >= 1 ? row[j - 1] : 0u;
-        v.a1 = row[j];
-        v.a2 = j + 1 < words ? row[j + 1] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        const int y = y0 + i;
+        if (y >= h) break;
+        Win3 v = in[i];
         bool dil = first_is_dilate != 0;
         for (int stage = 0; stage < nops; stage++) {
             const u32 ident = dil ? 0u : 0xffffffffu;
@@ -314,8 +322,9 @@ __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bit
             v = comb3(look(v, -ax, ident), look(v, kx - px - ax, ident), dil);
             dil = !dil;
         }
-        const u32 val = value_dev ? (u32)value_dev[b] : value;
-        expand16((v.a1 >> ((cx & 1) * 16)) & 0xffffu, val, dst.row(b, y) + (size_t)cx * 16);
+        u8* o = dst.row(b, y) + (size_t)j * 32;
+        expand16(v.a1 & 0xffffu, val, o);
+        if (rem > 16) expand16(v.a1 >> 16, val, o + 16);
     }
 }
 
@@ -378,19 +387,14 @@ __global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits
         // (if any) for row r once stage-1 row r + below is known.
         const int lag1 = below, lag2 = nops == 2 ? below : 0;
         const int y_first = r0 - nops * ay, y_last = r1 - 1 + lag1 + lag2;
-        u32 nxt = 0;
-        if (y_first >= 0 && y_first < h) nxt = col[(size_t)y_first * bpw];
-        for (int y = y_first; y <= y_last; y++) {
-            const u32 raw = nxt;
-            const int yn = y + 1;
-            if (yn >= 0 && yn < h && yn <= y_last) nxt = col[(size_t)yn * bpw];
+        auto step = [&](int y, u32 raw) {
             // stage 1 input: image row, or the stage's identity outside the image
             // (erode: ones; dilate, run as erosion of the complement: also ones)
             u32 in1 = 0xffffffffu;
             if (y >= 0 && y < h) in1 = ((dil0 ? ~raw : raw) & wmask) | ~wmask;
             u32 full1 = run_update<NS>(d1, in1, ky);
             const int c1 = y - lag1;
-            if (c1 < r0 - (nops == 2 ? ay : 0)) continue;
+            if (c1 < r0 - (nops == 2 ? ay : 0)) return;
             u32 s1 = dil0 ? ~full1 : full1;  // stage-1 result for row c1
             u32 out;
             int r;
@@ -401,18 +405,29 @@ __global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits
                 // stage 2 runs the opposite operation on the stage-1 rows; outside the image
                 // its input is its own identity
                 const bool dil1 = !dil0;
-                u32 in2;
+                u32 in2 = 0xffffffffu;
                 if (c1 >= 0 && c1 < h) in2 = ((dil1 ? ~s1 : s1) & wmask) | ~wmask;
-                else in2 = 0xffffffffu;
                 u32 full2 = run_update<NS>(d2, in2, ky);
                 out = dil1 ? ~full2 : full2;
                 r = c1 - lag2;
             }
-            if (r < r0 || r >= r1) continue;
+            if (r < r0 || r >= r1) return;
             u8* o = dst.row(b, r) + (size_t)j * 32;
             out &= wmask;
             expand16(out & 0xffffu, val, o);
             if (rem > 16) expand16(out >> 16, val, o + 16);
+        };
+        // four rows per trip: their loads are all in flight before the first is consumed
+        for (int y = y_first; y <= y_last; y += 4) {
+            u32 raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int yy = y + k;
+                raw[k] = (yy >= 0 && yy < h && yy <= y_last) ? col[(size_t)yy * bpw] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (y + k <= y_last) step(y + k, raw[k]);
         }
     }
 }
@@ -558,11 +573,16 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
         fast = e ? atoi(e) : 1;
     }
     if (fast && ky == 1 && kx > 1 && nops * ax <= 32 && nops * (kx - 1 - ax) <= 32) {
-        const int cpr = cdiv(w, 16);
-        const long long total = (long long)cpr * h * batch;
-        hipLaunchKernelGGL(k_bitmorph_h3, dim3(stream_grid(total, 256)), dim3(256), 0, st, bits, bpw, bsw, dst, w, h, cpr,
-                           total, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value, value_dev);
-        IPA_LAUNCH_CHECK();
+        const int words = cdiv(w, 32);
+        for (int b0 = 0; b0 < batch; b0 += 65535) {
+            const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            Plane db = dst;
+            db.p += (size_t)b0 * dst.stride;
+            hipLaunchKernelGGL(k_bitmorph_h3, rows_grid(words, h, nb), rows_block(), 0, st, bits + (size_t)b0 * bsw, bpw, bsw,
+                               db, w, h, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value,
+                               value_dev ? value_dev + b0 : nullptr);
+            IPA_LAUNCH_CHECK();
+        }
         return IPA_OK;
     }
     if (fast && kx == 1 && ky > 1 && ky < 256) {
