@@ -25,6 +25,7 @@ namespace {
 struct ProfRec {
     int stage;
     hipEvent_t a, b;
+    bool ok;
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -39,7 +40,7 @@ void prof_begin(int stage, hipStream_t st)
     ProfRec r;
     r.stage = stage;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    hipEventRecord(r.a, st);
+    r.ok = hipEventRecord(r.a, st) == hipSuccess;
     g_prof_open.push_back(r);
 }
 
@@ -49,7 +50,7 @@ void prof_end(int stage, hipStream_t st)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (size_t i = g_prof_open.size(); i-- > 0;)
         if (g_prof_open[i].stage == stage) {
-            hipEventRecord(g_prof_open[i].b, st);
+            if (hipEventRecord(g_prof_open[i].b, st) != hipSuccess) g_prof_open[i].ok = false;
             g_prof_recs.push_back(g_prof_open[i]);
             g_prof_open.erase(g_prof_open.begin() + (long)i);
             return;
@@ -82,12 +83,12 @@ IPA_EXPORT int ipa_profile_collect(double* ms, int* launches)
     }
     for (auto& r : g_prof_recs) {
         float t = 0;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+        if (r.ok && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms[r.stage] += t;
             launches[r.stage]++;
         }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof_recs.clear();
     return IPA_OK;

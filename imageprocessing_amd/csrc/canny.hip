@@ -288,7 +288,6 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     MagRow mp = {0, 0, 0, 0}, mc = {0, 0, 0, 0};  // magnitude rows yy-3, yy-2 (set as they appear)
     u32 dxc01 = 0, dxc23 = 0, dyc01 = 0, dyc23 = 0;  // gradients of row yy-2
     u32 gnext = stream_load_gray(src, b, y0, x, w, h);
-#pragma unroll 6
     for (int yy = y0; yy <= y1 + 1; yy++) {
         const u32 g = gnext;
         if (yy + 1 <= y1 + 1) gnext = stream_load_gray(src, b, yy + 1, x, w, h);

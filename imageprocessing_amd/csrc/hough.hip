@@ -27,7 +27,7 @@ struct Trig {
     float c[IPA_MAX_ANGLES];
 };
 
-__global__ __launch_bounds__(256) void k_hough_compact(Plane src, int w, int h, int cpr, long long chunks_per_img,
+__global__ __launch_bounds__(256) void k_hough_compact(Plane src, int w, int h, int cpr, int chunks_per_img,
                                                        u32* __restrict__ pts, size_t pts_stride, u32 cap,
                                                        int32_t* __restrict__ counts)
 {
@@ -36,14 +36,14 @@ __global__ __launch_bounds__(256) void k_hough_compact(Plane src, int w, int h, 
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* out = pts + (size_t)b * pts_stride;
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < chunks_per_img; base += step) {
-        long long c = base + tid;
+    const int step = (int)(gridDim.x * blockDim.x);  // <= 2^21; the host keeps chunks_per_img < 2^31 - 2^22
+    for (int base = (int)(blockIdx.x * blockDim.x); base < chunks_per_img; base += step) {
+        const int c = base + tid;
         u32 d[4] = {0, 0, 0, 0};
         int n = 0, cx = 0, y = 0;
         if (c < chunks_per_img) {
-            cx = (int)(c % cpr);
-            y = (int)(c / cpr);
+            y = c / cpr;
+            cx = c - y * cpr;
             n = min(16, w - cx * 16);
             uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
             d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
@@ -368,7 +368,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
         ProfScope ps(PROF_HOUGH_COMPACT, st);
         int cpr = cdiv(w, 16);
-        IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL, IPA_ERR_ARG, "HoughLines: image too large");
+        IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL - (1 << 22), IPA_ERR_ARG, "HoughLines: image too large");
         int cpi = cpr * h;
         unsigned gx = (unsigned)((cpi + 255) / 256);
         unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));

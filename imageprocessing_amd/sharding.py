@@ -63,6 +63,8 @@ def gather_to_rank0(local: np.ndarray, n_items: int, rank: int, world_size: int,
 def plane_checksums(planes: np.ndarray) -> np.ndarray:
     """Order-sensitive 64-bit checksum of each image of uint8[N, H, W] (host side)."""
     n = planes.shape[0]
+    if n == 0:  # a rank whose block is empty (more ranks than images)
+        return np.zeros(0, np.uint64)
     flat = planes.reshape(n, -1).astype(np.uint64)
     idx = (np.arange(flat.shape[1], dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) & np.uint64(0xFFFFFFFF)
     return (flat * idx[None, :]).sum(axis=1, dtype=np.uint64)

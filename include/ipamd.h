@@ -185,8 +185,9 @@ int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
 /* cv2.Canny(gray, t1, t2, apertureSize=3, L2gradient=False): lineDetection.py:9;
  * "New Version/comparison.py":13; "Version4 with Chatgpt/contour_detection.py":61;
  * newVersion3/detectHorizontalVerticalLines.py:61; "New Version/detectArrow.py":8.
- * Hysteresis iterates until no tile changes; this call synchronises `stream`
- * (once per convergence check). */
+ * Hysteresis runs to its fixed point inside one launch for images of at most
+ * 4096 tiles of 128x32 pixels; larger images are resolved region by region and
+ * the call then synchronises `stream` once per convergence check. */
 size_t ipa_canny_workspace_bytes(int width, int height, int batch);
 int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
                  uint8_t* dst, size_t dst_pitch, size_t dst_stride,
@@ -238,8 +239,8 @@ int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle,
  *   hlines = morphologyEx(thresh, OPEN, rect(horiz_len, 1), iterations)
  *   edges  = Canny(blur5x5 ? GaussianBlur(gray,(5,5),0) : gray, canny_lo, canny_hi)
  *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL)
- * The five output planes share one pitch/stride.  Synchronises `stream` as
- * ipa_canny_u8 does. */
+ * The five output planes share one pitch/stride.  Synchronises `stream` only
+ * where ipa_canny_u8 does. */
 size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points);
 int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
                      uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,

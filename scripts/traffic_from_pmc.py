@@ -1,0 +1,56 @@
+"""Turns the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_passes.sh into per-stage HBM traffic
+per launch (bytes), written as profiles/traffic.json -> {"<size>x<batch>": {stage: bytes}}.
+
+FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced
+streaming read at half its bytes (128-B requests tallied as 64 B), so it is doubled here;
+WRITE_SIZE is taken as is.
+usage: traffic_from_pmc.py <pmc dir> <key e.g. 4kx128> [out json]"""
+import collections, csv, glob, json, os, re, sys
+
+STAGE_OF = {
+    "k_bgr2gray": "gray_thresh_pack", "k_bitmorph_v": "open_vertical", "k_bitmorph_h3": "open_horizontal",
+    "k_bitmorph": "open_horizontal", "k_canny_stream": "canny_nms", "k_canny_nms": "canny_nms",
+    "k_hyst_tiles": "canny_hysteresis", "k_hyst_final": "canny_hysteresis", "k_hough_compact": "hough_compact",
+    "k_hough_vote": "hough_vote", "k_hough_peaks": "hough_peaks", "k_gauss5": "gaussian_blur",
+}
+
+
+def per_kernel(root, counter):
+    vals = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            k = re.sub(r"[<(].*", "", k)
+            vals[k].append(float(r["Counter_Value"]))
+    return vals
+
+
+def main():
+    root, key = sys.argv[1], sys.argv[2]
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")
+    fetch = per_kernel(os.path.join(root, "fetch"), "FETCH_SIZE")
+    write = per_kernel(os.path.join(root, "write"), "WRITE_SIZE")
+    stage = collections.defaultdict(float)
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        if k not in STAGE_OF:
+            continue
+        # the first launch of each kernel belongs to the planning run; all launches do the same work
+        f = 2.0 * 1024 * (sum(fetch[k]) / len(fetch[k])) if fetch.get(k) else 0.0
+        w = 1024.0 * (sum(write[k]) / len(write[k])) if write.get(k) else 0.0
+        stage[STAGE_OF[k]] += f + w
+        rows.append((k, len(fetch.get(k, [])), f, w))
+    data = {}
+    if os.path.exists(out):
+        data = json.load(open(out))
+    data[key] = {s: round(v) for s, v in stage.items()}
+    data.setdefault("_note", "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), rocprofv3 --pmc, separate passes")
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
+    for k, n, f, w in rows:
+        print(f"{k:20s} launches={n:4d} fetch={f/1e6:10.1f} MB  write={w/1e6:10.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
