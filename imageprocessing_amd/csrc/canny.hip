@@ -230,14 +230,16 @@ struct MagRow {
     u32 mL, mR;    // magnitude just left of pixel 0 / just right of pixel 3
 };
 
-__device__ __forceinline__ u32 stream_load_gray(const Plane& src, int b, int yy, int x, int w, int h)
+// Value of the same register in lane-1 / lane+1 (one DPP move each; lane 0 / lane 63 get 0).
+__device__ __forceinline__ u32 from_lane_below(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ u32 from_lane_above(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// per 16-bit half: max(a - b, 0)
+__device__ __forceinline__ u32 pk_sub_sat_u16(u32 a, u32 b)
 {
-    const u8* row = src.row(b, clampi(yy, 0, h - 1));
-    if (x >= 0 && x + 4 <= w) return *(const u32*)(row + x);
-    u32 v = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) v |= (u32)row[clampi(x + j, 0, w - 1)] << (8 * j);
-    return v;
+    us2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+    return __builtin_bit_cast(u32, r);
 }
 
 template <bool EMIT>
@@ -246,10 +248,13 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
                                                       CannyWs W, PointSink sink)
 {
     __shared__ u32 s_pts[EMIT ? 4 : 1][EMIT ? 256 : 1];  // per wave: edge pixels waiting to be appended
-    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform values are forced into scalar registers so that the row loop, the row
+    // addresses and every "whole wave" decision below run on the scalar unit
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long wave_id = (long long)blockIdx.x * 4 + wv;
     if (wave_id >= nwaves) return;
     const int lane = threadIdx.x & 63;
-    u32* pbuf = s_pts[EMIT ? (threadIdx.x >> 6) : 0];
+    u32* pbuf = s_pts[EMIT ? wv : 0];
     u32 fill = 0;  // wave-uniform
     // append the buffered points to the image's list: one atomic per flush, coalesced stores
     auto flush = [&](int bimg) {
@@ -274,56 +279,95 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     const u32 cm01 = ((x >= 0 && x < w) ? 0x0000ffffu : 0u) | ((x + 1 >= 0 && x + 1 < w) ? 0xffff0000u : 0u);
     const u32 cm23 = ((x + 2 >= 0 && x + 2 < w) ? 0x0000ffffu : 0u) | ((x + 3 >= 0 && x + 3 < w) ? 0xffff0000u : 0u);
     const bool writer = lane >= 1 && lane <= 62 && x < w;
+    // Every lane reads one (possibly unaligned) 32-bit word that lies inside the row; the byte
+    // selectors below pick the replicated border pixel for columns outside the image while they
+    // widen the four bytes to 16-bit pairs, so there is no separate border path.
+    const int xc = clampi(x, 0, w - 4);
+    u32 sel01, sel23;
+    {
+        const u32 i0 = (u32)(clampi(x, 0, w - 1) - xc), i1 = (u32)(clampi(x + 1, 0, w - 1) - xc);
+        const u32 i2 = (u32)(clampi(x + 2, 0, w - 1) - xc), i3 = (u32)(clampi(x + 3, 0, w - 1) - xc);
+        sel01 = PAIR_SEL(i0, i1);
+        sel23 = PAIR_SEL(i2, i3);
+    }
+    const u8* const simg = src.p + (size_t)b * src.stride;  // wave-uniform base, 32-bit offsets below
+    u8* const dimg = dst.p + (size_t)b * dst.stride;
+    const u32 spitch = (u32)src.pitch, dpitch = (u32)dst.pitch;
+    auto load_row = [&](int yy) -> u32 {
+        const u32 off = (u32)clampi(yy, 0, h - 1) * spitch + (u32)xc;
+        return *(const u32*)(simg + (size_t)off);
+    };
+    u8* const weak_row0 = W.has_weak + (size_t)b * tiles_y * tiles_x + x / TW;
 
     // gray rows yy-2 (a), yy-1 (bq) as 16-bit pairs (columns 0,1 and 2,3)
     s2 a0, a1, bq0, bq1;
     {
-        u32 g = stream_load_gray(src, b, y0 - 2, x, w, h);
-        a0 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(0, 1)));
-        a1 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(2, 3)));
-        g = stream_load_gray(src, b, y0 - 1, x, w, h);
-        bq0 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(0, 1)));
-        bq1 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(2, 3)));
+        u32 g = load_row(y0 - 2);
+        a0 = as_s2(__builtin_amdgcn_perm(0, g, sel01));
+        a1 = as_s2(__builtin_amdgcn_perm(0, g, sel23));
+        g = load_row(y0 - 1);
+        bq0 = as_s2(__builtin_amdgcn_perm(0, g, sel01));
+        bq1 = as_s2(__builtin_amdgcn_perm(0, g, sel23));
     }
     MagRow mp = {0, 0, 0, 0}, mc = {0, 0, 0, 0};  // magnitude rows yy-3, yy-2 (set as they appear)
     u32 dxc01 = 0, dxc23 = 0, dyc01 = 0, dyc23 = 0;  // gradients of row yy-2
-    u32 gnext = stream_load_gray(src, b, y0, x, w, h);
-    for (int yy = y0; yy <= y1 + 1; yy++) {
-        const u32 g = gnext;
-        if (yy + 1 <= y1 + 1) gnext = stream_load_gray(src, b, yy + 1, x, w, h);
-        const s2 c0 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(0, 1))), c1 = as_s2(__builtin_amdgcn_perm(0, g, PAIR_SEL(2, 3)));
-        // ---- gradients and magnitude of row yy-1 (gray rows yy-2, yy-1, yy)
-        const s2 vs0 = a0 + bq0 + bq0 + c0, vs1 = a1 + bq1 + bq1 + c1;
-        const s2 vd0 = c0 - a0, vd1 = c1 - a1;
-        const u32 vsL = __shfl_up(as_u32(vs1), 1), vsR = __shfl_down(as_u32(vs0), 1);
-        const u32 vdL = __shfl_up(as_u32(vd1), 1), vdR = __shfl_down(as_u32(vd0), 1);
-        const s2 vsm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vs0), vsL, 16));          // columns -1, 0
-        const s2 vs12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vs1), as_u32(vs0), 16));   // columns 1, 2
-        const s2 vs34 = as_s2(__builtin_amdgcn_alignbit(vsR, as_u32(vs1), 16));           // columns 3, 4
-        const s2 vdm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd0), vdL, 16));
-        const s2 vd12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd1), as_u32(vd0), 16));
-        const s2 vd34 = as_s2(__builtin_amdgcn_alignbit(vdR, as_u32(vd1), 16));
-        const s2 dx01 = vs12 - vsm10, dx23 = vs34 - vs12;
-        const s2 dy01 = vdm10 + vd0 + vd0 + vd12, dy23 = vd12 + vd1 + vd1 + vd34;
-        MagRow mn;
-        {
-            const bool row_in = yy - 1 >= 0 && yy - 1 < h;
-            const u32 m01 = as_u32(__builtin_elementwise_abs(dx01) + __builtin_elementwise_abs(dy01));
-            const u32 m23 = as_u32(__builtin_elementwise_abs(dx23) + __builtin_elementwise_abs(dy23));
-            mn.m01 = row_in ? (m01 & cm01) : 0u;
-            mn.m23 = row_in ? (m23 & cm23) : 0u;
-            mn.mL = __shfl_up(mn.m23, 1) >> 16;
-            mn.mR = __shfl_down(mn.m01, 1) & 0xffffu;
+    // A gray row is "flat" when every pixel the wave sees has one value; three equal flat rows
+    // in a row have zero gradients, so the Sobel step is skipped (wave-uniform test).
+    int flat_run = 0;      // consecutive flat rows of value flat_val ending at the newest row
+    u32 flat_val = 0;
+    bool mc_zero = true;   // magnitude row yy-2 is known to be all zero
+    const u32 low2 = (u32)min(max(low, 0), 0x7fff) * 0x00010001u;  // magnitudes never exceed 2040
+    // three gray rows are always in flight ahead of the row being consumed
+    u32 gq[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gq[k] = load_row(y0 + k);
+    // fixed trip count (rows past the image are clamped reads and skipped writes) so that the
+    // loop can be unrolled by three, the period of the rolling row registers
+#pragma unroll 3
+    for (int it = 0; it < ST_ROWS + 2; it++) {
+        const int yy = y0 + it;
+        const u32 g = gq[it % 3];
+        gq[it % 3] = load_row(yy + 3);
+        const s2 c0 = as_s2(__builtin_amdgcn_perm(0, g, sel01)), c1 = as_s2(__builtin_amdgcn_perm(0, g, sel23));
+        const u32 val_c = (u32)__builtin_amdgcn_readfirstlane((int)as_u32(c0));
+        const bool flat_c = (val_c >> 16) == (val_c & 0xffffu) && __all(as_u32(c0) == val_c && as_u32(c1) == val_c);
+        flat_run = flat_c ? (val_c == flat_val ? flat_run + 1 : 1) : 0;
+        flat_val = val_c;
+        // rows outside the image have magnitude 0 as well
+        const bool mn_zero = flat_run >= 3 || yy - 1 < 0 || yy - 1 >= h;
+        MagRow mn = {0, 0, 0, 0};
+        s2 dx01 = {0, 0}, dx23 = {0, 0}, dy01 = {0, 0}, dy23 = {0, 0};
+        if (!mn_zero) {
+            // ---- gradients and magnitude of row yy-1 (gray rows yy-2, yy-1, yy)
+            const s2 vs0 = a0 + bq0 + bq0 + c0, vs1 = a1 + bq1 + bq1 + c1;
+            const s2 vd0 = c0 - a0, vd1 = c1 - a1;
+            const u32 vsL = from_lane_below(as_u32(vs1)), vsR = from_lane_above(as_u32(vs0));
+            const u32 vdL = from_lane_below(as_u32(vd1)), vdR = from_lane_above(as_u32(vd0));
+            const s2 vsm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vs0), vsL, 16));          // columns -1, 0
+            const s2 vs12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vs1), as_u32(vs0), 16));   // columns 1, 2
+            const s2 vs34 = as_s2(__builtin_amdgcn_alignbit(vsR, as_u32(vs1), 16));           // columns 3, 4
+            const s2 vdm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd0), vdL, 16));
+            const s2 vd12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd1), as_u32(vd0), 16));
+            const s2 vd34 = as_s2(__builtin_amdgcn_alignbit(vdR, as_u32(vd1), 16));
+            dx01 = vs12 - vsm10;
+            dx23 = vs34 - vs12;
+            dy01 = vdm10 + vd0 + vd0 + vd12;
+            dy23 = vd12 + vd1 + vd1 + vd34;
+            mn.m01 = as_u32(__builtin_elementwise_abs(dx01) + __builtin_elementwise_abs(dy01)) & cm01;
+            mn.m23 = as_u32(__builtin_elementwise_abs(dx23) + __builtin_elementwise_abs(dy23)) & cm23;
+            mn.mL = from_lane_below(mn.m23) >> 16;
+            mn.mR = from_lane_above(mn.m01) & 0xffffu;
         }
         // ---- non-maximum suppression of row yy-2 (magnitude rows yy-3 = mp, yy-2 = mc, yy-1 = mn)
         const int ry = yy - 2;
-        if (ry >= y0 && ry < y1) {
-            const int cm[4] = {(int)(mc.m01 & 0xffffu), (int)(mc.m01 >> 16), (int)(mc.m23 & 0xffffu), (int)(mc.m23 >> 16)};
-            u32 cand = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) cand |= (cm[j] > low ? 1u : 0u) << j;
+        if (it >= 2 && ry < y1) {
             u32 codes = 0;
-            if (__any(cand != 0)) {
+            // any magnitude of the row above the low threshold?  (per 16-bit half: max(m - low, 0))
+            if (!mc_zero && __any((pk_sub_sat_u16(mc.m01, low2) | pk_sub_sat_u16(mc.m23, low2)) != 0)) {
+                const int cm[4] = {(int)(mc.m01 & 0xffffu), (int)(mc.m01 >> 16), (int)(mc.m23 & 0xffffu), (int)(mc.m23 >> 16)};
+                u32 cand = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) cand |= (cm[j] > low ? 1u : 0u) << j;
                 const int vP[6] = {(int)mp.mL, (int)(mp.m01 & 0xffffu), (int)(mp.m01 >> 16), (int)(mp.m23 & 0xffffu), (int)(mp.m23 >> 16), (int)mp.mR};
                 const int vC[6] = {(int)mc.mL, cm[0], cm[1], cm[2], cm[3], (int)mc.mR};
                 const int vN[6] = {(int)mn.mL, (int)(mn.m01 & 0xffffu), (int)(mn.m01 >> 16), (int)(mn.m23 & 0xffffu), (int)(mn.m23 >> 16), (int)mn.mR};
@@ -353,10 +397,9 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
                 }
             }
             if (writer) {
-                *(u32*)(dst.row(b, ry) + x) = codes;
+                *(u32*)(dimg + (size_t)((u32)ry * dpitch + (u32)x)) = codes;
                 // any WEAK byte (value 1, top bit clear) flags the 128x32 tile for the hysteresis
-                if (codes & ~(codes >> 7) & 0x01010101u)
-                    W.has_weak[((size_t)b * tiles_y + ry / TH) * tiles_x + x / TW] = 1;
+                if (codes & ~(codes >> 7) & 0x01010101u) weak_row0[(u32)(ry / TH) * (u32)tiles_x] = 1;
             }
             if (EMIT) {
                 // strong pixels (255) of this row -> the wave's buffer, in lane order per pixel column
@@ -380,7 +423,7 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         }
         // ---- roll the window
         a0 = bq0; a1 = bq1; bq0 = c0; bq1 = c1;
-        mp = mc; mc = mn;
+        mp = mc; mc = mn; mc_zero = mn_zero;
         dxc01 = as_u32(dx01); dxc23 = as_u32(dx23); dyc01 = as_u32(dy01); dyc23 = as_u32(dy23);
     }
     flush(b);
@@ -656,7 +699,10 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     }
     {
         ProfScope ps(PROF_CANNY_NMS, st);
-        if (mode == 1) {
+        // the streaming kernel reads whole 32-bit words inside a row and uses 32-bit offsets within an image
+        const bool stream_ok = w >= 4 && (unsigned long long)h * src.pitch < 0xffffffffull && (unsigned long long)h * dst.pitch < 0xffffffffull;
+        if (mode == 1 && (stream_ok || sink.pts)) {
+            IPA_REQUIRE(stream_ok, IPA_ERR_ARG, "Canny: image too small or too large for the fused edge-list path");
             IPA_HIP(hipMemsetAsync(W.has_weak, 0, ntiles, st));
             const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;

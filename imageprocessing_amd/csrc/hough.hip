@@ -240,6 +240,103 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
         for (int col = seg_lo + tid; col < seg_hi; col += VOTE_THREADS) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
 }
 
+// Voting with the per-angle constants in scalar registers.  TG angles per workgroup are
+// unrolled at compile time: cos/sin come straight from the kernel arguments (scalar loads),
+// the LDS byte offset of each angle's row is made wave-uniform with readfirstlane, and one
+// vote costs two packed float instructions (multiply pair, add, add of the rounding constant,
+// each shared by two points) plus one shift-add for the LDS address.
+template <int TG>
+__global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig T)
+{
+    extern __shared__ __align__(16) u32 hist[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int grp = blockIdx.x;
+    const int n0 = grp * TG;
+    const int tg = min(TG, A.numangle - n0);
+    const int half = (A.numrho - 1) / 2;
+    const int span = A.span_max;
+    const int ncols = A.numrho + 2;
+
+    float cg[TG], sg[TG];
+    int col0[TG];
+    u32 k4[TG];  // byte offset such that (float bits of r + 1.5*2^23) * 4 + k4 addresses the bin
+#pragma unroll
+    for (int g = 0; g < TG; g++) {
+        const int n = min(n0 + g, A.numangle - 1);
+        const float c = T.c[n], s = T.s[n];
+        // smallest reachable rho: the float ops are monotone, so it lies at a corner
+        const float xw = (float)(A.w - 1), yh = (float)(A.h - 1);
+        const int r00 = rho_index(0.f, 0.f, c, s), r10 = rho_index(xw, 0.f, c, s);
+        const int r01 = rho_index(0.f, yh, c, s), r11 = rho_index(xw, yh, c, s);
+        const int rmin = __builtin_amdgcn_readfirstlane(min(min(r00, r10), min(r01, r11)));
+        cg[g] = c;
+        sg[g] = s;
+        col0[g] = rmin + half + 1;
+        k4[g] = (u32)(half + 1 - col0[g] - 0x4B400000 + g * span) * 4u;
+    }
+    for (int i = tid; i < TG * span; i += VOTE_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    const u32 npts = min((u32)A.counts[b], A.cap);
+    const u32* pts = A.pts + (size_t)b * A.pts_stride;
+    const uint4* pts4 = (const uint4*)pts;
+    const u32 nfull = npts >> 2;
+    char* const hb = (char*)hist;
+    const f2 magic = {12582912.0f, 12582912.0f};
+    u32 i = tid;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (i < nfull) cur = pts4[i];
+    while (i < nfull) {
+        const u32 inext = i + VOTE_THREADS;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (inext < nfull) nxt = pts4[inext];
+        const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
+        const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
+        const f2 y01 = {(float)(cur.x >> 16), (float)(cur.y >> 16)};
+        const f2 y23 = {(float)(cur.z >> 16), (float)(cur.w >> 16)};
+#pragma unroll
+        for (int g = 0; g < TG; g++) {
+            if (g < tg) {
+                const f2 r01 = (x01 * cg[g] + y01 * sg[g]) + magic;  // every op rounds on its own
+                const f2 r23 = (x23 * cg[g] + y23 * sg[g]) + magic;
+                atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.x) << 2) + k4[g])), 1u);
+                atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.y) << 2) + k4[g])), 1u);
+                atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.x) << 2) + k4[g])), 1u);
+                atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.y) << 2) + k4[g])), 1u);
+            }
+        }
+        cur = nxt;
+        i = inext;
+    }
+    // the last 0..3 points
+    for (u32 j = nfull * 4 + tid; j < npts; j += VOTE_THREADS) {
+        const u32 p = pts[j];
+        const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+            if (g < tg) atomicAdd(&hist[g * span + rho_index(x, y, cg[g], sg[g]) + half + 1 - col0[g]], 1u);
+    }
+    __syncthreads();
+
+    int32_t* acc = A.accum + (size_t)b * A.accum_stride;
+#pragma unroll
+    for (int g = 0; g < TG; g++) {
+        if (g < tg) {
+            int32_t* row = acc + (size_t)(n0 + g + 1) * ncols;
+            const u32* hg = hist + g * span;
+            for (int col = tid; col < ncols; col += VOTE_THREADS) {
+                const int idx = col - col0[g];
+                row[col] = (unsigned)idx < (unsigned)span ? (int32_t)hg[idx] : 0;
+            }
+        }
+    }
+    if (grp == 0)
+        for (int col = tid; col < ncols; col += VOTE_THREADS) acc[col] = 0;
+    if (grp == A.groups - 1)
+        for (int col = tid; col < ncols; col += VOTE_THREADS) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
+}
+
 // Four cells per lane and trip (independent loads); the four neighbours are read only for
 // the few cells above the threshold.
 __global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__ accum, size_t accum_stride,
@@ -435,6 +532,15 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     if (tg < 1) tg = 1;
     if (tg > VOTE_MAX_TG) tg = VOTE_MAX_TG;
     while (tg > 1 && (long long)cdiv(numangle, tg) * A.nseg * batch < 1024) tg--;
+    // the compile-time unrolled kernel exists for 2, 4 and 8 angles per workgroup
+    static int scalar_ok = -1;  // IPA_VOTE_SCALAR=0 selects the generic kernel
+    if (scalar_ok < 0) {
+        const char* e = getenv("IPA_VOTE_SCALAR");
+        scalar_ok = e ? atoi(e) : 1;
+    }
+    int tgs = 0;
+    if (scalar_ok && !pack16 && !check && !A.seg_walk) tgs = tg >= 8 ? 8 : tg >= 4 ? 4 : tg >= 2 ? 2 : 0;
+    if (tgs) tg = tgs;
     A.tg = tg;
     A.groups = cdiv(numangle, tg);
     size_t lds = (size_t)tg * span_words * 4;
@@ -443,6 +549,9 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
     ProfScope ps(PROF_HOUGH_VOTE, st);
@@ -453,7 +562,13 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.counts = point_counts + b0;
         Ab.accum = accum + (size_t)b0 * accum_stride;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
-        if (pack16 && !check)
+        if (tgs == 8)
+            hipLaunchKernelGGL(k_hough_vote_s<8>, grid, block, lds, st, Ab, T);
+        else if (tgs == 4)
+            hipLaunchKernelGGL(k_hough_vote_s<4>, grid, block, lds, st, Ab, T);
+        else if (tgs == 2)
+            hipLaunchKernelGGL(k_hough_vote_s<2>, grid, block, lds, st, Ab, T);
+        else if (pack16 && !check)
             hipLaunchKernelGGL((k_hough_vote<true, false>), grid, block, lds, st, Ab, T);
         else if (pack16)
             hipLaunchKernelGGL((k_hough_vote<true, true>), grid, block, lds, st, Ab, T);
