@@ -227,7 +227,7 @@ constexpr int ST_COLS = 248;
 
 struct MagRow {
     u32 m01, m23;  // magnitudes of the lane's 4 pixels (16-bit pairs)
-    u32 mL, mR;    // magnitude just left of pixel 0 / just right of pixel 3
+    u32 nL, nR;    // the left lane's m23 (columns -2,-1) / the right lane's m01 (columns 4,5)
 };
 
 // Value of the same register in lane-1 / lane+1 (one DPP move each; lane 0 / lane 63 get 0).
@@ -235,11 +235,63 @@ __device__ __forceinline__ u32 from_lane_below(u32 v) { return (u32)__builtin_am
 __device__ __forceinline__ u32 from_lane_above(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(u32 v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ u32 us2_u32(us2 v) { return __builtin_bit_cast(u32, v); }
 // per 16-bit half: max(a - b, 0)
-__device__ __forceinline__ u32 pk_sub_sat_u16(u32 a, u32 b)
+__device__ __forceinline__ us2 sub_sat(us2 a, us2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ u32 pk_sub_sat_u16(u32 a, u32 b) { return us2_u32(sub_sat(as_us2(a), as_us2(b))); }
+// Non-maximum suppression of two adjacent pixels at once, in packed 16-bit arithmetic and
+// without branches.  m = magnitudes, ax/ay = |dx|,|dy|, sgn = dx ^ dy; CL/CR = magnitudes one
+// column to the left/right in the same row, PL/Pc/PR and NL/Nc/NR the three neighbours in the
+// row above / below; low2/high2 = thresholds in both halves, span2 = 255 - WEAK in both halves
+// (WEAK must be 1).  Returns per half 0, WEAK or 255.
+//   horizontal  <=>  |dy| * 2^15 < |dx| * 13573          <=>  |dy| <  ceil(|dx| * 13573 / 2^15)
+//   vertical    <=>  |dy| * 2^15 > |dx| * (13573 + 2^16)  <=>  |dy| >  floor(|dx| * 13573 / 2^15) + 2 |dx|
+// (|dx| * 13573 is a multiple of 2^15 only for dx = 0), and floor(|dx| * 13573 / 2^15) is
+// ((|dx| * 53) + ((|dx| * 5) >> 8)) >> 7 with every intermediate below 2^16 for |dx| <= 1020.
+// Written as one block of packed instructions: the optimiser otherwise splits these idioms
+// into per-half compares and selects, which doubles the instruction count.
+static_assert(WEAK == 1, "nms_pair encodes WEAK as 1");
+__device__ __forceinline__ u32 nms_pair(u32 m, u32 ax, u32 ay, u32 sgn, u32 CL, u32 CR, u32 PL, u32 Pc, u32 PR,
+                                        u32 NL, u32 Nc, u32 NR, u32 low2, u32 high2, u32 span2)
 {
-    us2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
-    return __builtin_bit_cast(u32, r);
+    u32 out, t0, t1, t2, t3, t4;
+    asm("v_pk_mul_lo_u16 %[t0], %[ax], 5 op_sel_hi:[1,0]\n\t"
+        "v_pk_lshrrev_b16 %[t0], 8, %[t0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mad_u16 %[t0], %[ax], 53, %[t0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_lshrrev_b16 %[t0], 7, %[t0] op_sel_hi:[0,1]\n\t"       // f = floor(|dx| * 13573 / 2^15)
+        "v_pk_min_u16 %[t1], %[ax], 1 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_u16 %[t1], %[t0], %[t1]\n\t"                       // ceil(...)
+        "v_pk_sub_u16 %[t1], %[t1], %[ay] clamp\n\t"
+        "v_pk_min_u16 %[t1], %[t1], 1 op_sel_hi:[1,0]\n\t"           // hb = 1: horizontal gradient
+        "v_pk_mad_u16 %[t0], %[ax], 2, %[t0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_sub_u16 %[t0], %[ay], %[t0] clamp\n\t"
+        "v_pk_min_u16 %[t0], %[t0], 1 op_sel_hi:[1,0]\n\t"           // vb = 1: vertical gradient
+        "v_pk_sub_u16 %[t2], 1, %[t1] op_sel_hi:[0,1]\n\t"
+        "v_pk_sub_u16 %[t2], %[t2], %[t0]\n\t"                       // 1 on the diagonals
+        "v_pk_sub_u16 %[t1], 0, %[t1] op_sel_hi:[0,1]\n\t"           // hb, vb -> 0xffff masks
+        "v_pk_sub_u16 %[t0], 0, %[t0] op_sel_hi:[0,1]\n\t"
+        "v_pk_ashrrev_i16 %[t3], 15, %[sg] op_sel_hi:[0,1]\n\t"      // 0xffff: dx, dy of opposite sign
+        "v_bfi_b32 %[t4], %[t3], %[PR], %[PL]\n\t"
+        "v_bfi_b32 %[t4], %[t0], %[Pc], %[t4]\n\t"
+        "v_bfi_b32 %[t4], %[t1], %[CL], %[t4]\n\t"                   // neighbour that must be below m
+        "v_bfi_b32 %[t3], %[t3], %[NL], %[NR]\n\t"
+        "v_bfi_b32 %[t3], %[t0], %[Nc], %[t3]\n\t"
+        "v_bfi_b32 %[t3], %[t1], %[CR], %[t3]\n\t"                   // neighbour that must not exceed m
+        "v_pk_add_u16 %[t3], %[t3], %[t2]\n\t"                       //   (must be below m on the diagonals)
+        "v_pk_sub_u16 %[t3], %[t3], %[m] clamp\n\t"                  // != 0: fails
+        "v_pk_max_u16 %[t4], %[t4], %[low]\n\t"
+        "v_pk_sub_u16 %[t4], %[m], %[t4] clamp\n\t"
+        "v_pk_min_u16 %[t4], %[t4], 1 op_sel_hi:[1,0]\n\t"           // 1: m > neighbour and m > low
+        "v_pk_sub_u16 %[t4], %[t4], %[t3] clamp\n\t"                 // 1: local maximum
+        "v_pk_sub_u16 %[t0], %[m], %[high] clamp\n\t"
+        "v_pk_min_u16 %[t0], %[t0], 1 op_sel_hi:[1,0]\n\t"           // 1: above the high threshold
+        "v_pk_mad_u16 %[t0], %[t0], %[span], 1 op_sel_hi:[1,1,0]\n\t"
+        "v_pk_mul_lo_u16 %[out], %[t4], %[t0]"
+        : [out] "=&v"(out), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
+        : [m] "v"(m), [ax] "v"(ax), [ay] "v"(ay), [sg] "v"(sgn), [CL] "v"(CL), [CR] "v"(CR), [PL] "v"(PL), [Pc] "v"(Pc),
+          [PR] "v"(PR), [NL] "v"(NL), [Nc] "v"(Nc), [NR] "v"(NR), [low] "s"(low2), [high] "s"(high2), [span] "s"(span2));
+    return out;
 }
 
 template <bool EMIT>
@@ -270,9 +322,11 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         __builtin_amdgcn_wave_barrier();
         fill = 0;
     };
-    const int sx = (int)(wave_id % strips_x);
-    long long t = wave_id / strips_x;
-    const int band = (int)(t % bands), b = (int)(t / bands);
+    // (the host keeps the number of waves below 2^31: 32-bit divisions)
+    const u32 wid = (u32)wave_id;
+    const u32 t = wid / (u32)strips_x;
+    const int sx = (int)(wid - t * (u32)strips_x);
+    const int b = (int)(t / (u32)bands), band = (int)(t - (u32)b * (u32)bands);
     const int x = sx * ST_COLS - 4 + 4 * lane;
     const int y0 = band * ST_ROWS, y1 = min(y0 + ST_ROWS, h);
     // magnitude is 0 outside the image
@@ -310,13 +364,15 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         bq1 = as_s2(__builtin_amdgcn_perm(0, g, sel23));
     }
     MagRow mp = {0, 0, 0, 0}, mc = {0, 0, 0, 0};  // magnitude rows yy-3, yy-2 (set as they appear)
-    u32 dxc01 = 0, dxc23 = 0, dyc01 = 0, dyc23 = 0;  // gradients of row yy-2
+    u32 axc01 = 0, axc23 = 0, ayc01 = 0, ayc23 = 0, sgc01 = 0, sgc23 = 0;  // |dx|, |dy|, dx ^ dy of row yy-2
     // A gray row is "flat" when every pixel the wave sees has one value; three equal flat rows
     // in a row have zero gradients, so the Sobel step is skipped (wave-uniform test).
     int flat_run = 0;      // consecutive flat rows of value flat_val ending at the newest row
     u32 flat_val = 0;
-    bool mc_zero = true;   // magnitude row yy-2 is known to be all zero
-    const u32 low2 = (u32)min(max(low, 0), 0x7fff) * 0x00010001u;  // magnitudes never exceed 2040
+    bool mp_zero = true, mc_zero = true;   // magnitude rows yy-3 / yy-2 are known to be all zero
+    const u32 low2 = (u32)__builtin_amdgcn_readfirstlane(min(max(low, 0), 0x7fff) * 0x00010001);  // magnitudes never exceed 2040
+    const u32 high2 = (u32)__builtin_amdgcn_readfirstlane(min(max(high, 0), 0x7fff) * 0x00010001);
+    const u32 span2 = (u32)__builtin_amdgcn_readfirstlane((int)((255u - WEAK) * 0x00010001u));
     // three gray rows are always in flight ahead of the row being consumed
     u32 gq[3];
 #pragma unroll
@@ -329,15 +385,22 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         const u32 g = gq[it % 3];
         gq[it % 3] = load_row(yy + 3);
         const s2 c0 = as_s2(__builtin_amdgcn_perm(0, g, sel01)), c1 = as_s2(__builtin_amdgcn_perm(0, g, sel23));
-        const u32 val_c = (u32)__builtin_amdgcn_readfirstlane((int)as_u32(c0));
-        const bool flat_c = (val_c >> 16) == (val_c & 0xffffu) && __all(as_u32(c0) == val_c && as_u32(c1) == val_c);
+        // every pixel value the wave uses comes from the loaded words, so the row is flat when
+        // all words equal one word of four equal bytes
+        const u32 val_c = (u32)__builtin_amdgcn_readfirstlane((int)g);
+        const bool flat_c = val_c == __builtin_rotateleft32(val_c, 8) && __all(g == val_c);
         flat_run = flat_c ? (val_c == flat_val ? flat_run + 1 : 1) : 0;
         flat_val = val_c;
         // rows outside the image have magnitude 0 as well
         const bool mn_zero = flat_run >= 3 || yy - 1 < 0 || yy - 1 >= h;
-        MagRow mn = {0, 0, 0, 0};
-        s2 dx01 = {0, 0}, dx23 = {0, 0}, dy01 = {0, 0}, dy23 = {0, 0};
-        if (!mn_zero) {
+        MagRow mn;
+        u32 ax01, ax23, ay01, ay23, sg01, sg23;
+        if (mn_zero) {
+            // The row is known to be zero: the *_zero flags stand for the zeros and nothing reads
+            // the gradients, so the registers are only declared written (no instruction).
+            asm("" : "=v"(mn.m01), "=v"(mn.m23), "=v"(mn.nL), "=v"(mn.nR));
+            asm("" : "=v"(ax01), "=v"(ax23), "=v"(ay01), "=v"(ay23), "=v"(sg01), "=v"(sg23));
+        } else {
             // ---- gradients and magnitude of row yy-1 (gray rows yy-2, yy-1, yy)
             const s2 vs0 = a0 + bq0 + bq0 + c0, vs1 = a1 + bq1 + bq1 + c1;
             const s2 vd0 = c0 - a0, vd1 = c1 - a1;
@@ -349,14 +412,17 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
             const s2 vdm10 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd0), vdL, 16));
             const s2 vd12 = as_s2(__builtin_amdgcn_alignbit(as_u32(vd1), as_u32(vd0), 16));
             const s2 vd34 = as_s2(__builtin_amdgcn_alignbit(vdR, as_u32(vd1), 16));
-            dx01 = vs12 - vsm10;
-            dx23 = vs34 - vs12;
-            dy01 = vdm10 + vd0 + vd0 + vd12;
-            dy23 = vd12 + vd1 + vd1 + vd34;
-            mn.m01 = as_u32(__builtin_elementwise_abs(dx01) + __builtin_elementwise_abs(dy01)) & cm01;
-            mn.m23 = as_u32(__builtin_elementwise_abs(dx23) + __builtin_elementwise_abs(dy23)) & cm23;
-            mn.mL = from_lane_below(mn.m23) >> 16;
-            mn.mR = from_lane_above(mn.m01) & 0xffffu;
+            const s2 dx01 = vs12 - vsm10, dx23 = vs34 - vs12;
+            const s2 dy01 = vdm10 + vd0 + vd0 + vd12, dy23 = vd12 + vd1 + vd1 + vd34;
+            const s2 adx01 = __builtin_elementwise_abs(dx01), adx23 = __builtin_elementwise_abs(dx23);
+            const s2 ady01 = __builtin_elementwise_abs(dy01), ady23 = __builtin_elementwise_abs(dy23);
+            ax01 = as_u32(adx01); ax23 = as_u32(adx23); ay01 = as_u32(ady01); ay23 = as_u32(ady23);
+            sg01 = as_u32(dx01) ^ as_u32(dy01);
+            sg23 = as_u32(dx23) ^ as_u32(dy23);
+            mn.m01 = as_u32(adx01 + ady01) & cm01;
+            mn.m23 = as_u32(adx23 + ady23) & cm23;
+            mn.nL = from_lane_below(mn.m23);
+            mn.nR = from_lane_above(mn.m01);
         }
         // ---- non-maximum suppression of row yy-2 (magnitude rows yy-3 = mp, yy-2 = mc, yy-1 = mn)
         const int ry = yy - 2;
@@ -364,37 +430,18 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
             u32 codes = 0;
             // any magnitude of the row above the low threshold?  (per 16-bit half: max(m - low, 0))
             if (!mc_zero && __any((pk_sub_sat_u16(mc.m01, low2) | pk_sub_sat_u16(mc.m23, low2)) != 0)) {
-                const int cm[4] = {(int)(mc.m01 & 0xffffu), (int)(mc.m01 >> 16), (int)(mc.m23 & 0xffffu), (int)(mc.m23 >> 16)};
-                u32 cand = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) cand |= (cm[j] > low ? 1u : 0u) << j;
-                const int vP[6] = {(int)mp.mL, (int)(mp.m01 & 0xffffu), (int)(mp.m01 >> 16), (int)(mp.m23 & 0xffffu), (int)(mp.m23 >> 16), (int)mp.mR};
-                const int vC[6] = {(int)mc.mL, cm[0], cm[1], cm[2], cm[3], (int)mc.mR};
-                const int vN[6] = {(int)mn.mL, (int)(mn.m01 & 0xffffu), (int)(mn.m01 >> 16), (int)(mn.m23 & 0xffffu), (int)(mn.m23 >> 16), (int)mn.mR};
-                const int dxs[4] = {(int)(dxc01 << 16) >> 16, (int)dxc01 >> 16, (int)(dxc23 << 16) >> 16, (int)dxc23 >> 16};
-                const int dys[4] = {(int)(dyc01 << 16) >> 16, (int)dyc01 >> 16, (int)(dyc23 << 16) >> 16, (int)dyc23 >> 16};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (!((cand >> j) & 1u)) continue;
-                    const int m = vC[j + 1], dx = dxs[j], dy = dys[j];
-                    const int ax = abs(dx), ay = abs(dy) << 15;
-                    const int tg22x = ax * 13573;
-                    bool is_max;
-                    if (ay < tg22x) {
-                        is_max = m > vC[j] && m >= vC[j + 2];
-                    } else {
-                        const int tg67x = tg22x + (ax << 16);
-                        if (ay > tg67x) {
-                            is_max = m > vP[j + 1] && m >= vN[j + 1];
-                        } else {
-                            const bool neg = (dx ^ dy) < 0;  // s = -1
-                            const int pv = neg ? vP[j + 2] : vP[j];
-                            const int nv = neg ? vN[j] : vN[j + 2];
-                            is_max = m > pv && m > nv;
-                        }
-                    }
-                    if (is_max) codes |= (m > high ? 255u : (u32)WEAK) << (8 * j);
-                }
+                const MagRow zero = {0, 0, 0, 0};
+                const MagRow mpv = mp_zero ? zero : mp, mnv = mn_zero ? zero : mn;
+                // neighbour pairs: columns (-1,0), (1,2), (3,4) of the three rows
+                const u32 cA = __builtin_amdgcn_alignbit(mc.m01, mc.nL, 16), cB = __builtin_amdgcn_alignbit(mc.m23, mc.m01, 16),
+                          cC = __builtin_amdgcn_alignbit(mc.nR, mc.m23, 16);
+                const u32 pA = __builtin_amdgcn_alignbit(mpv.m01, mpv.nL, 16), pB = __builtin_amdgcn_alignbit(mpv.m23, mpv.m01, 16),
+                          pC = __builtin_amdgcn_alignbit(mpv.nR, mpv.m23, 16);
+                const u32 nA = __builtin_amdgcn_alignbit(mnv.m01, mnv.nL, 16), nB = __builtin_amdgcn_alignbit(mnv.m23, mnv.m01, 16),
+                          nC = __builtin_amdgcn_alignbit(mnv.nR, mnv.m23, 16);
+                const u32 k01 = nms_pair(mc.m01, axc01, ayc01, sgc01, cA, cB, pA, mpv.m01, pB, nA, mnv.m01, nB, low2, high2, span2);
+                const u32 k23 = nms_pair(mc.m23, axc23, ayc23, sgc23, cB, cC, pB, mpv.m23, pC, nB, mnv.m23, nC, low2, high2, span2);
+                codes = __builtin_amdgcn_perm(k23, k01, 0x06040200u);  // low byte of each 16-bit code
             }
             if (writer) {
                 *(u32*)(dimg + (size_t)((u32)ry * dpitch + (u32)x)) = codes;
@@ -423,8 +470,8 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         }
         // ---- roll the window
         a0 = bq0; a1 = bq1; bq0 = c0; bq1 = c1;
-        mp = mc; mc = mn; mc_zero = mn_zero;
-        dxc01 = as_u32(dx01); dxc23 = as_u32(dx23); dyc01 = as_u32(dy01); dyc23 = as_u32(dy23);
+        mp = mc; mc = mn; mp_zero = mc_zero; mc_zero = mn_zero;
+        axc01 = ax01; axc23 = ax23; ayc01 = ay01; ayc23 = ay23; sgc01 = sg01; sgc23 = sg23;
     }
     flush(b);
 }
@@ -706,7 +753,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
             IPA_HIP(hipMemsetAsync(W.has_weak, 0, ntiles, st));
             const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;
-            IPA_REQUIRE(nwaves / 4 + 1 < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
+            IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
             if (sink.pts)
                 hipLaunchKernelGGL(k_canny_stream<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h,
                                    strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
