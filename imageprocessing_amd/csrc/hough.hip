@@ -83,6 +83,103 @@ __global__ __launch_bounds__(256) void k_hough_compact(Plane src, int w, int h, 
     }
 }
 
+// Compaction with one global atomic per block of 4 rows x 4096 pixels.  blockIdx.x is the
+// IMAGE, so the workgroups resident at any time append to many different lists (atomics on
+// one address are served one at a time).  Wave `ty` owns one row; lane tx reads the 16-pixel
+// chunks tx, tx+64, tx+128, tx+192 of the block's span, all four loads in flight together,
+// and the points are listed in raster order (the voting kernel is fastest when the points
+// of one vote instruction are spread along rows rather than clustered in two dimensions).
+// Points are staged in LDS and appended with coalesced stores (written directly when a
+// block holds more than the stage).
+constexpr int CP_STAGE = 4096;
+
+// bit 0 of each byte of x -> 4 adjacent bits
+__device__ __forceinline__ u32 bytes_to_bits(u32 x) { return ((x & 0x01010101u) * 0x10204080u) >> 28; }
+// 1 in bit 0 of every non-zero byte
+__device__ __forceinline__ u32 nonzero_bytes(u32 v) { return ((v | ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; }
+
+__global__ __launch_bounds__(256) void k_hough_compact2(Plane src, int w, int h, int cpr, u32* __restrict__ pts,
+                                                        size_t pts_stride, u32 cap, int32_t* __restrict__ counts, int spread)
+{
+    __shared__ u32 s_pts[CP_STAGE];
+    __shared__ u32 row_tot[4 * ROWS_PER_LANE];
+    __shared__ u32 s_base;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
+    const int cx0 = (int)blockIdx.y * 64 * ROWS_PER_LANE + lane;
+    // the four rows of a block are a quarter of the image apart
+    const int y = (int)blockIdx.z + wave * (int)gridDim.z;
+    uint4 a[ROWS_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_LANE; k++) {
+        a[k] = make_uint4(0, 0, 0, 0);
+        if (cx0 + 64 * k < cpr && y < h) a[k] = *(const uint4*)(src.row(b, y) + (size_t)(cx0 + 64 * k) * 16);
+    }
+    // one wave scan per 1024-pixel piece of the row
+    u32 m[ROWS_PER_LANE], excl[ROWS_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_LANE; k++) {
+        const int n = w - (cx0 + 64 * k) * 16;  // pixels of the chunk inside the image
+        const u32 keep = n >= 16 ? 0xffffu : (n > 0 ? (1u << n) - 1u : 0u);
+        m[k] = (bytes_to_bits(nonzero_bytes(a[k].x)) | (bytes_to_bits(nonzero_bytes(a[k].y)) << 4) |
+                (bytes_to_bits(nonzero_bytes(a[k].z)) << 8) | (bytes_to_bits(nonzero_bytes(a[k].w)) << 12)) & keep;
+        const u32 cnt = __popc(m[k]);
+        u32 scan = cnt;  // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(scan, o);
+            if (lane >= o) scan += t;
+        }
+        excl[k] = scan - cnt;
+        if (lane == 63) row_tot[wave * ROWS_PER_LANE + k] = scan;
+    }
+    __syncthreads();
+    u32 total = 0, row_base[ROWS_PER_LANE] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4 * ROWS_PER_LANE; r++) {
+        const u32 t = row_tot[r];
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_LANE; k++)
+            if (r == wave * ROWS_PER_LANE + k) row_base[k] = total;
+        total += t;
+    }
+    if (total == 0) return;  // uniform over the block
+    if (tid == 0) s_base = (u32)atomicAdd(&counts[b], (int32_t)total);
+    u32* out = pts + (size_t)b * pts_stride;
+    const bool staged = total <= (u32)CP_STAGE;
+    u32 gbase = 0;
+    if (!staged) {
+        __syncthreads();
+        gbase = s_base;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_LANE; k++) {
+        const u32 xy = ((u32)y << 16) | (u32)((cx0 + 64 * k) * 16);
+        u32 pos = gbase + row_base[k] + excl[k];
+        u32 mk = m[k];
+        while (mk) {
+            const int i = __ffs(mk) - 1;
+            mk &= mk - 1;
+            if (staged)
+                s_pts[pos] = xy + (u32)i;
+            else if (pos < cap)
+                out[pos] = xy + (u32)i;
+            pos++;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        const u32 base = s_base;
+        // Stored entry p holds staged point (p * M) mod total, M a prime that does not divide
+        // total: neighbouring list entries are then M raster positions apart, so the 64 points
+        // of one vote instruction lie on different features and rarely share an LDS bin.
+        u32 M = 1;
+        if (spread && total >= 128) M = total % 61 ? 61 : (total % 67 ? 67 : 71);
+        for (u32 i = tid; i < total; i += 256)
+            if (base + i < cap) out[base + i] = s_pts[(i * M) % total];
+    }
+}
+
 struct VoteArgs {
     const u32* pts;
     size_t pts_stride;
@@ -245,7 +342,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 // the LDS byte offset of each angle's row is made wave-uniform with readfirstlane, and one
 // vote costs two packed float instructions (multiply pair, add, add of the rounding constant,
 // each shared by two points) plus one shift-add for the LDS address.
-template <int TG>
+template <int TG, bool LANE1>
 __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig T)
 {
     extern __shared__ __align__(16) u32 hist[];
@@ -284,13 +381,26 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
     const u32 nfull = npts >> 2;
     char* const hb = (char*)hist;
     const f2 magic = {12582912.0f, 12582912.0f};
-    u32 i = tid;
+    // Four points per lane and trip.  LANE1 = false: four consecutive list entries per lane (one
+    // 16-byte load); LANE1 = true: neighbouring lanes hold neighbouring entries and a lane's
+    // four points are 512 entries apart (four coalesced 4-byte loads).
+    const u32 ntrips = LANE1 ? npts / (4 * VOTE_THREADS) : (nfull + VOTE_THREADS - 1) / VOTE_THREADS;
+    const u32 tail0 = LANE1 ? ntrips * (4 * VOTE_THREADS) : nfull * 4;
+    auto load4 = [&](u32 trip) -> uint4 {
+        if (LANE1) {
+            const u32* q = pts + (size_t)trip * (4 * VOTE_THREADS) + tid;
+            return make_uint4(q[0], q[VOTE_THREADS], q[2 * VOTE_THREADS], q[3 * VOTE_THREADS]);
+        }
+        return pts4[trip * VOTE_THREADS + tid];
+    };
+    auto valid = [&](u32 trip) -> bool { return LANE1 ? trip < ntrips : trip * VOTE_THREADS + tid < nfull; };
+    u32 i = 0;
     uint4 cur = make_uint4(0, 0, 0, 0);
-    if (i < nfull) cur = pts4[i];
-    while (i < nfull) {
-        const u32 inext = i + VOTE_THREADS;
+    if (valid(0)) cur = load4(0);
+    while (valid(i)) {
+        const u32 inext = i + 1;
         uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (inext < nfull) nxt = pts4[inext];
+        if (valid(inext)) nxt = load4(inext);
         const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
         const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
         const f2 y01 = {(float)(cur.x >> 16), (float)(cur.y >> 16)};
@@ -309,8 +419,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
         cur = nxt;
         i = inext;
     }
-    // the last 0..3 points
-    for (u32 j = nfull * 4 + tid; j < npts; j += VOTE_THREADS) {
+    // the points left over by the four-at-a-time loop
+    for (u32 j = tail0 + tid; j < npts; j += VOTE_THREADS) {
         const u32 p = pts[j];
         const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
 #pragma unroll
@@ -464,20 +574,36 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     if (!points_ready) {
         IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
         ProfScope ps(PROF_HOUGH_COMPACT, st);
-        int cpr = cdiv(w, 16);
-        IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL - (1 << 22), IPA_ERR_ARG, "HoughLines: image too large");
-        int cpi = cpr * h;
-        unsigned gx = (unsigned)((cpi + 255) / 256);
-        unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
-        if (capx < 1) capx = 1;
-        if (gx > capx) gx = capx;
-        for (int b0 = 0; b0 < batch; b0 += 65535) {
-            int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-            Plane sb = src;
-            sb.p += (size_t)b0 * src.stride;
-            hipLaunchKernelGGL(k_hough_compact, dim3(gx, nb), dim3(256), 0, st, sb, w, h, cpr, cpi,
-                               pts + (size_t)b0 * pts_stride, pts_stride, cap, point_counts + b0);
+        const int cpr = cdiv(w, 16);
+        static int cmode = -1;  // IPA_COMPACT_MODE=0 selects the grid-stride kernel
+        if (cmode < 0) {
+            const char* e = getenv("IPA_COMPACT_MODE");
+            cmode = e ? atoi(e) : 1;
+        }
+        if (cmode == 1) {
+            const dim3 grid((unsigned)batch, (unsigned)cdiv(cpr, 64 * ROWS_PER_LANE), (unsigned)cdiv(h, 4));
+            static int spread = -1;  // IPA_COMPACT_SPREAD=0 keeps raster order inside a block
+            if (spread < 0) {
+                const char* e = getenv("IPA_COMPACT_SPREAD");
+                spread = e ? atoi(e) : 1;
+            }
+            hipLaunchKernelGGL(k_hough_compact2, grid, rows_block(), 0, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
             IPA_LAUNCH_CHECK();
+        } else {
+            IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL - (1 << 22), IPA_ERR_ARG, "HoughLines: image too large");
+            int cpi = cpr * h;
+            unsigned gx = (unsigned)((cpi + 255) / 256);
+            unsigned capx = (unsigned)(8192 / (batch < 8192 ? batch : 8192));
+            if (capx < 1) capx = 1;
+            if (gx > capx) gx = capx;
+            for (int b0 = 0; b0 < batch; b0 += 65535) {
+                int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+                Plane sb = src;
+                sb.p += (size_t)b0 * src.stride;
+                hipLaunchKernelGGL(k_hough_compact, dim3(gx, nb), dim3(256), 0, st, sb, w, h, cpr, cpi,
+                                   pts + (size_t)b0 * pts_stride, pts_stride, cap, point_counts + b0);
+                IPA_LAUNCH_CHECK();
+            }
         }
     }
     // geometry of the vote kernel
@@ -524,7 +650,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     static int lds_kb = -1;  // IPA_VOTE_LDS_KB: LDS budget per workgroup
     if (lds_kb < 0) {
         const char* e = getenv("IPA_VOTE_LDS_KB");
-        lds_kb = e ? atoi(e) : 78;
+        lds_kb = e ? atoi(e) : 40;
         if (lds_kb < 8) lds_kb = 8;
         if (lds_kb > 150) lds_kb = 150;
     }
@@ -538,6 +664,11 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         const char* e = getenv("IPA_VOTE_SCALAR");
         scalar_ok = e ? atoi(e) : 1;
     }
+    static int lane1 = -1;  // IPA_VOTE_LANE1=1: neighbouring lanes vote for neighbouring list entries
+    if (lane1 < 0) {
+        const char* e = getenv("IPA_VOTE_LANE1");
+        lane1 = e ? atoi(e) : 0;
+    }
     int tgs = 0;
     if (scalar_ok && !pack16 && !check && !A.seg_walk) tgs = tg >= 8 ? 8 : tg >= 4 ? 4 : tg >= 2 ? 2 : 0;
     if (tgs) tg = tgs;
@@ -549,9 +680,12 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
     ProfScope ps(PROF_HOUGH_VOTE, st);
@@ -562,12 +696,18 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.counts = point_counts + b0;
         Ab.accum = accum + (size_t)b0 * accum_stride;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
-        if (tgs == 8)
-            hipLaunchKernelGGL(k_hough_vote_s<8>, grid, block, lds, st, Ab, T);
+        if (tgs == 8 && lane1)
+            hipLaunchKernelGGL((k_hough_vote_s<8, true>), grid, block, lds, st, Ab, T);
+        else if (tgs == 4 && lane1)
+            hipLaunchKernelGGL((k_hough_vote_s<4, true>), grid, block, lds, st, Ab, T);
+        else if (tgs == 2 && lane1)
+            hipLaunchKernelGGL((k_hough_vote_s<2, true>), grid, block, lds, st, Ab, T);
+        else if (tgs == 8)
+            hipLaunchKernelGGL((k_hough_vote_s<8, false>), grid, block, lds, st, Ab, T);
         else if (tgs == 4)
-            hipLaunchKernelGGL(k_hough_vote_s<4>, grid, block, lds, st, Ab, T);
+            hipLaunchKernelGGL((k_hough_vote_s<4, false>), grid, block, lds, st, Ab, T);
         else if (tgs == 2)
-            hipLaunchKernelGGL(k_hough_vote_s<2>, grid, block, lds, st, Ab, T);
+            hipLaunchKernelGGL((k_hough_vote_s<2, false>), grid, block, lds, st, Ab, T);
         else if (pack16 && !check)
             hipLaunchKernelGGL((k_hough_vote<true, false>), grid, block, lds, st, Ab, T);
         else if (pack16)
