@@ -188,7 +188,8 @@ def main():
 
     def step():
         fe.enqueue(bgr)
-        rc = L.ipa_hough_peaks_i32(fe.accum.data_ptr(), fe.accum.stride(0), fe.na, fe.nr, batch, args.hough_threshold,
+        rc = L.ipa_hough_peaks_i32(fe.accum.data_ptr(), fe.accum.stride(0), fe.seg_max.data_ptr(), fe.na, fe.nr, batch,
+                                   args.hough_threshold,
                                    keys.data_ptr(), cap, peak_counts.data_ptr(), stream)
         if rc:
             raise RuntimeError(_native.last_error())

@@ -49,10 +49,11 @@ SIGNATURES = {
     "ipa_canny_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _d, _d, _vp, _sz, _vp]),
     "ipa_hough_dims": (_i, [_i, _i, _d, _d, C.POINTER(_i), C.POINTER(_i)]),
     "ipa_hough_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "ipa_hough_accum_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _d, _d, _vp, _sz, _i, _vp, _vp, _sz, _vp]),
-    "ipa_hough_peaks_i32": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "ipa_hough_segments": (_i, [_i]),
+    "ipa_hough_accum_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _d, _d, _vp, _sz, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ipa_hough_peaks_i32": (_i, [_vp, _sz, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ipa_front_end_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "ipa_front_end_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _i, _vp,
+    "ipa_front_end_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _i, _vp,
                               _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _sz, _vp]),
 }
 

@@ -132,8 +132,8 @@ IPA_EXPORT size_t ipa_front_end_workspace_bytes(int width, int height, int batch
 
 IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
                                 uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch,
-                                size_t plane_stride, int32_t* accum, size_t accum_stride, int max_points,
-                                int32_t* point_counts, int width, int height, int batch, int thresh_val, int vert_len,
+                                size_t plane_stride, int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                                int max_points, int32_t* point_counts, int width, int height, int batch, int thresh_val, int vert_len,
                                 int horiz_len, int iterations, double canny_lo, double canny_hi, int blur5x5, void* ws,
                                 size_t ws_bytes, void* stream)
 {
@@ -209,7 +209,7 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     rc = run_canny(csrc, E, width, height, batch, (int)floor(lo), (int)floor(hi), canny_ws, L.canny_bytes, sink, st);
     if (rc) return rc;
     if (accum)
-        rc = run_hough_accum(E, width, height, batch, 1.0, M_PI / 180, accum, accum_stride, max_points, point_counts,
+        rc = run_hough_accum(E, width, height, batch, 1.0, M_PI / 180, accum, accum_stride, seg_max, max_points, point_counts,
                              hough_ws, L.hough_bytes, fused != 0, st);
     return rc;
 }

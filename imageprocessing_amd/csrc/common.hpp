@@ -158,5 +158,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
 
 size_t hough_ws_bytes(int w, int h, int batch, int max_points);
 PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, void* ws);
+int hough_segments(int numrho);
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready, hipStream_t st);
+                    int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready,
+                    hipStream_t st);

@@ -194,6 +194,8 @@ struct VoteArgs {
     int seg_cols;  // columns (of numrho+2) per slice
     int span_max;  // LDS bins per angle
     int seg_walk;  // 1: each lane walks a contiguous segment of the point list
+    int32_t* segmax;  // optional: per image, angle and 512-column segment the largest count
+    int nsegs;        // segments per accumulator row
 };
 
 __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
@@ -202,6 +204,7 @@ __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
 }
 
 constexpr int VOTE_THREADS = 512;
+constexpr int HOUGH_SEG = VOTE_THREADS;  // columns per segment of the per-row maxima
 constexpr int VOTE_MAX_TG = 16;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -441,6 +444,27 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
             }
         }
     }
+    if (A.segmax) {
+        // largest count of every HOUGH_SEG-column segment of every row: one wave per (row, segment)
+        int32_t* sm = A.segmax + ((size_t)b * A.numangle + n0) * A.nsegs;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int q = wave; q < tg * A.nsegs; q += VOTE_THREADS / 64) {
+            const int g = q / A.nsegs, j = q - g * A.nsegs;
+            int c0 = 0;
+#pragma unroll
+            for (int gg = 0; gg < TG; gg++)
+                if (gg == g) c0 = col0[gg];
+            u32 mx = 0;
+#pragma unroll
+            for (int t = 0; t < HOUGH_SEG / 64; t++) {
+                const int idx = j * HOUGH_SEG + t * 64 + lane - c0;
+                if ((unsigned)idx < (unsigned)span) mx = max(mx, hist[g * span + idx]);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, o));
+            if (lane == 0) sm[q] = (int32_t)mx;
+        }
+    }
     if (grp == 0)
         for (int col = tid; col < ncols; col += VOTE_THREADS) acc[col] = 0;
     if (grp == A.groups - 1)
@@ -496,6 +520,60 @@ __global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__
     }
 }
 
+// Peak search guided by the per-segment maxima the voting kernel left behind: a cell can
+// only be a peak if it exceeds the threshold, so segments whose maximum does not are never
+// read.  One wave per accumulator row.
+__global__ __launch_bounds__(256) void k_hough_peaks_seg(const int32_t* __restrict__ accum, size_t accum_stride,
+                                                         const int32_t* __restrict__ segmax, int nsegs, int numangle,
+                                                         int numrho, int threshold, u64* __restrict__ keys, int capacity,
+                                                         int32_t* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = (int)blockIdx.x * 4 + wv;
+    if (n >= numangle) return;
+    const int lane = threadIdx.x & 63;
+    const int ncols = numrho + 2;
+    const int32_t* acc = accum + (size_t)b * accum_stride;
+    const int32_t* row = acc + (size_t)(n + 1) * ncols;
+    const int32_t* sm = segmax + ((size_t)b * numangle + n) * nsegs;
+    for (int j0 = 0; j0 < nsegs; j0 += 64) {
+      // 64 segment maxima at a time: one load, one ballot, then only the hot segments
+      unsigned long long hot = __ballot(j0 + lane < nsegs && sm[j0 + lane] > threshold);
+      while (hot) {
+        const int j = j0 + __ffsll((long long)hot) - 1;
+        hot &= hot - 1;
+        // all cells of the segment first (independent loads), then the neighbours of the few
+        // cells above the threshold
+        int32_t v[HOUGH_SEG / 64];
+#pragma unroll
+        for (int t = 0; t < HOUGH_SEG / 64; t++) {
+            const int col = j * HOUGH_SEG + t * 64 + lane;
+            v[t] = (col >= 1 && col <= numrho) ? row[col] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < HOUGH_SEG / 64; t++) {
+            const int col = j * HOUGH_SEG + t * 64 + lane;
+            bool peak = false;
+            if (v[t] > threshold && col >= 1 && col <= numrho)
+                peak = v[t] > row[col - 1] && v[t] >= row[col + 1] && v[t] > row[col - ncols] && v[t] >= row[col + ncols];
+            const unsigned long long m = __ballot(peak);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int32_t basepos = 0;
+                if (lane == leader) basepos = atomicAdd(&counts[b], (int32_t)__popcll(m));
+                basepos = __shfl(basepos, leader);
+                if (peak) {
+                    const int pos = basepos + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < capacity)
+                        keys[(size_t)b * capacity + pos] = ((u64)(u32)v[t] << 32) | (u64)(0xffffffffu - (u32)((n + 1) * ncols + col));
+                }
+            }
+        }
+      }
+    }
+}
+
 void hough_dims(int w, int h, double rho, double theta, int* numangle, int* numrho)
 {
     float frho = (float)rho, ftheta = (float)theta;
@@ -544,8 +622,11 @@ PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, 
 
 // `points_ready`: the per-image point lists (layout of hough_point_sink) and point_counts were
 // already produced by the Canny kernels; otherwise they are compacted from `src` here.
+int hough_segments(int numrho) { return cdiv(numrho + 2, HOUGH_SEG); }
+
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                    int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready, hipStream_t st)
+                    int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready,
+                    hipStream_t st)
 {
     IPA_REQUIRE(w <= 65535 && h <= 65535, IPA_ERR_ARG, "HoughLines: image larger than 65535 pixels on a side");
     int numangle, numrho;
@@ -658,7 +739,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     if (tg < 1) tg = 1;
     if (tg > VOTE_MAX_TG) tg = VOTE_MAX_TG;
     while (tg > 1 && (long long)cdiv(numangle, tg) * A.nseg * batch < 1024) tg--;
-    // the compile-time unrolled kernel exists for 2, 4 and 8 angles per workgroup
+    // the compile-time unrolled kernel exists for 1, 2, 4 and 8 angles per workgroup
     static int scalar_ok = -1;  // IPA_VOTE_SCALAR=0 selects the generic kernel
     if (scalar_ok < 0) {
         const char* e = getenv("IPA_VOTE_SCALAR");
@@ -670,16 +751,22 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         lane1 = e ? atoi(e) : 0;
     }
     int tgs = 0;
-    if (scalar_ok && !pack16 && !check && !A.seg_walk) tgs = tg >= 8 ? 8 : tg >= 4 ? 4 : tg >= 2 ? 2 : 0;
+    if (scalar_ok && !pack16 && !check && !A.seg_walk) tgs = tg >= 8 ? 8 : tg >= 4 ? 4 : tg >= 2 ? 2 : 1;
     if (tgs) tg = tgs;
     A.tg = tg;
     A.groups = cdiv(numangle, tg);
+    A.nsegs = hough_segments(numrho);
+    A.segmax = tgs ? seg_max : nullptr;
+    if (seg_max && !tgs)  // this kernel variant does not produce the maxima: mark every segment as worth reading
+        IPA_HIP(hipMemsetD32Async((hipDeviceptr_t)seg_max, 0x7fffffff, (size_t)batch * numangle * A.nsegs, st));
     size_t lds = (size_t)tg * span_words * 4;
     if (lds > 48 * 1024 && !g_vote_attr_set) {
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -695,6 +782,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.pts = pts + (size_t)b0 * pts_stride;
         Ab.counts = point_counts + b0;
         Ab.accum = accum + (size_t)b0 * accum_stride;
+        if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
         if (tgs == 8 && lane1)
             hipLaunchKernelGGL((k_hough_vote_s<8, true>), grid, block, lds, st, Ab, T);
@@ -708,6 +796,10 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             hipLaunchKernelGGL((k_hough_vote_s<4, false>), grid, block, lds, st, Ab, T);
         else if (tgs == 2)
             hipLaunchKernelGGL((k_hough_vote_s<2, false>), grid, block, lds, st, Ab, T);
+        else if (tgs == 1 && lane1)
+            hipLaunchKernelGGL((k_hough_vote_s<1, true>), grid, block, lds, st, Ab, T);
+        else if (tgs == 1)
+            hipLaunchKernelGGL((k_hough_vote_s<1, false>), grid, block, lds, st, Ab, T);
         else if (pack16 && !check)
             hipLaunchKernelGGL((k_hough_vote<true, false>), grid, block, lds, st, Ab, T);
         else if (pack16)
@@ -726,9 +818,12 @@ IPA_EXPORT size_t ipa_hough_workspace_bytes(int width, int height, int batch, in
     return hough_ws_bytes(width, height, batch, max_points);
 }
 
+IPA_EXPORT int ipa_hough_segments(int numrho) { return numrho >= 1 ? hough_segments(numrho) : 0; }
+
 IPA_EXPORT int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, int width, int height,
                                   int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                                  int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, void* stream)
+                                  int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes,
+                                  void* stream)
 {
     IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
     IPA_REQUIRE(rho > 0 && theta > 0, IPA_ERR_ARG, "HoughLines: rho and theta must be positive");
@@ -741,17 +836,19 @@ IPA_EXPORT int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t s
         for (int b = 0; b < batch; b++)
             IPA_HIP(hipMemsetAsync(accum + (size_t)b * accum_stride, 0, sizeof(int32_t) * (size_t)(na + 2) * (nr + 2), st));
         IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+        if (seg_max) IPA_HIP(hipMemsetAsync(seg_max, 0, sizeof(int32_t) * (size_t)batch * na * hough_segments(nr), st));
         return IPA_OK;
     }
     Plane s = mkplane(src, src_pitch, src_stride);
     IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
                 "HoughLines: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
-    return run_hough_accum(s, width, height, batch, rho, theta, accum, accum_stride, max_points, point_counts, ws,
-                           ws_bytes, false, st);
+    return run_hough_accum(s, width, height, batch, rho, theta, accum, accum_stride, seg_max, max_points, point_counts,
+                           ws, ws_bytes, false, st);
 }
 
-IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle, int numrho, int batch,
-                                   int threshold, uint64_t* keys, int capacity, int32_t* peak_counts, void* stream)
+IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, const int32_t* seg_max, int numangle,
+                                   int numrho, int batch, int threshold, uint64_t* keys, int capacity,
+                                   int32_t* peak_counts, void* stream)
 {
     IPA_REQUIRE(numangle >= 1 && numrho >= 1 && batch >= 0 && capacity >= 0, IPA_ERR_ARG, "HoughLines: bad peak arguments");
     if (batch == 0) return IPA_OK;
@@ -767,6 +864,14 @@ IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, in
     ProfScope ps(PROF_HOUGH_PEAKS, st);
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        if (seg_max) {
+            const int nsegs = hough_segments(numrho);
+            hipLaunchKernelGGL(k_hough_peaks_seg, dim3((unsigned)cdiv(numangle, 4), nb), dim3(256), 0, st,
+                               accum + (size_t)b0 * accum_stride, accum_stride, seg_max + (size_t)b0 * numangle * nsegs, nsegs,
+                               numangle, numrho, threshold, (u64*)keys + (size_t)b0 * capacity, capacity, peak_counts + b0);
+            IPA_LAUNCH_CHECK();
+            continue;
+        }
         hipLaunchKernelGGL(k_hough_peaks, dim3(gx, nb), dim3(256), 0, st, accum + (size_t)b0 * accum_stride,
                            accum_stride, numangle, numrho, threshold, (u64*)keys + (size_t)b0 * capacity, capacity,
                            peak_counts + b0);

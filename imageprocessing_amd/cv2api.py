@@ -255,19 +255,21 @@ def hough_dims(width, height, rho, theta):
     return na.value, nr.value
 
 
-def hough_accumulator(image, rho, theta):
-    """Vote accumulator of cv2.HoughLines as a device tensor int32[numangle+2, numrho+2].
+def hough_accumulator(image, rho, theta, with_seg_max=False):
+    """Vote accumulator of cv2.HoughLines as a device tensor int32[numangle+2, numrho+2]
+    (and, on request, the per-segment maxima int32[numangle, segments] that speed up the peak search).
 
     cv2 does not expose it; it is returned here because parity is defined on its counts."""
     L = _native.lib()
     s = upload(image, 1)
     na, nr = hough_dims(s.width, s.height, rho, theta)
     acc = torch.empty((na + 2, nr + 2), dtype=torch.int32, device=s.t.device)
+    seg = torch.empty((na, L.ipa_hough_segments(nr)), dtype=torch.int32, device=s.t.device)
     counts = torch.zeros(1, dtype=torch.int32, device=s.t.device)
     ws = workspace(L.ipa_hough_workspace_bytes(s.width, s.height, 1, 0))
     check(L.ipa_hough_accum_u8(s.ptr, s.pitch, s.stride, s.width, s.height, 1, float(rho), float(theta), acc.data_ptr(),
-                               acc.numel(), 0, counts.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()))
-    return acc
+                               acc.numel(), seg.data_ptr(), 0, counts.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()))
+    return (acc, seg) if with_seg_max else acc
 
 
 def lines_from_keys(keys: np.ndarray, numrho: int, rho: float, theta: float):
@@ -283,14 +285,16 @@ def lines_from_keys(keys: np.ndarray, numrho: int, rho: float, theta: float):
     return np.stack([out_rho, out_theta], axis=1).astype(np.float32)[:, None, :]
 
 
-def hough_peaks(acc: torch.Tensor, threshold: int, capacity: int = 4096) -> np.ndarray:
-    """Unsorted 64-bit peak keys of one accumulator (device), growing the buffer as needed."""
+def hough_peaks(acc: torch.Tensor, threshold: int, capacity: int = 4096, seg_max: torch.Tensor = None) -> np.ndarray:
+    """Unsorted 64-bit peak keys of one accumulator (device), growing the buffer as needed.
+    ``seg_max`` = the per-segment maxima produced together with ``acc`` (optional)."""
     L = _native.lib()
     na, nr = acc.shape[0] - 2, acc.shape[1] - 2
     while True:
         keys = torch.empty(max(capacity, 1), dtype=torch.int64, device=acc.device)
         cnt = torch.zeros(1, dtype=torch.int32, device=acc.device)
-        check(L.ipa_hough_peaks_i32(acc.data_ptr(), acc.numel(), na, nr, 1, int(threshold), keys.data_ptr(), capacity,
+        check(L.ipa_hough_peaks_i32(acc.data_ptr(), acc.numel(), seg_max.data_ptr() if seg_max is not None else None, na, nr, 1,
+                                    int(threshold), keys.data_ptr(), capacity,
                                     cnt.data_ptr(), stream_ptr()))
         n = int(cnt.item())
         if n <= capacity:
@@ -307,8 +311,8 @@ def HoughLines(image, rho, theta, threshold, lines=None, srn=0, stn=0, min_theta
         raise error("HoughLines: only min_theta=0, max_theta=pi is supported")
     if rho <= 0 or theta <= 0:
         raise error("HoughLines: rho and theta must be greater 0")
-    acc = hough_accumulator(image, rho, theta)
-    keys = hough_peaks(acc, int(threshold))
+    acc, seg = hough_accumulator(image, rho, theta, with_seg_max=True)
+    keys = hough_peaks(acc, int(threshold), seg_max=seg)
     if keys.size == 0:
         return None
     out = lines_from_keys(keys, acc.shape[1] - 2, rho, theta)

@@ -56,9 +56,12 @@ class FrontEnd:
         if self.hough:
             self.accum = torch.empty((max(self.batch, 1), self.na + 2, self.nr + 2), dtype=torch.int32, device=dev)
             self.point_counts = torch.zeros(max(self.batch, 1), dtype=torch.int32, device=dev)
+            self.seg_max = torch.zeros((max(self.batch, 1), self.na, L.ipa_hough_segments(self.nr)), dtype=torch.int32,
+                                       device=dev)
         else:
             self.accum = None
             self.point_counts = None
+            self.seg_max = None
         self._alloc_ws()
 
     def _alloc_ws(self):
@@ -81,6 +84,7 @@ class FrontEnd:
         check(L.ipa_front_end_u8(
             bgr.ptr, bgr.pitch, bgr.stride, p[0].ptr, p[1].ptr, p[2].ptr, p[3].ptr, p[4].ptr, p[0].pitch, p[0].stride,
             self.accum.data_ptr() if self.hough else None, self.accum.stride(0) if self.hough else 0,
+            self.seg_max.data_ptr() if self.hough else None,
             self.max_points, self.point_counts.data_ptr() if self.hough else None,
             self.width, self.height, self.batch, self.thresh_val, self.vert_len, self.horiz_len, self.iterations,
             float(self.canny[0]), float(self.canny[1]), 1 if self.blur else 0,
@@ -101,7 +105,7 @@ class FrontEnd:
         """Per-image cv2.HoughLines output from the accumulators of the last run."""
         out = []
         for b in range(self.batch):
-            keys = cv2api.hough_peaks(self.accum[b], int(threshold))
+            keys = cv2api.hough_peaks(self.accum[b], int(threshold), seg_max=self.seg_max[b])
             out.append(cv2api.lines_from_keys(keys, self.nr, 1.0, np.pi / 180) if keys.size else None)
         return out
 

@@ -202,8 +202,17 @@ int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
  * a one-bin border as int32[(numangle+2)*(numrho+2)]. */
 int ipa_hough_dims(int width, int height, double rho, double theta, int* numangle, int* numrho);
 
+/* Number of 512-column segments of one padded accumulator row (numrho+2 columns):
+ * the unit of the optional `seg_max` arrays below. */
+int ipa_hough_segments(int numrho);
+
 /* Vote accumulator for every non-zero pixel.  `accum` = int32 device array,
  * image b at accum + b*accum_stride (elements); fully written by the call.
+ * `seg_max` (optional, may be NULL) = int32[batch][numangle][ipa_hough_segments(numrho)]:
+ * receives the largest count of every 512-column segment of every accumulator row
+ * (an upper bound is also legal); ipa_hough_peaks_i32 uses it to skip segments that
+ * cannot hold a peak.  It has no counterpart in cv2, which keeps the accumulator
+ * private.
  * `max_points` bounds the per-image list of non-zero pixels kept in scratch
  * (0 = width*height); `point_counts` (int32[batch], device) receives the true
  * number of non-zero pixels -- if any exceeds max_points the accumulator of
@@ -211,7 +220,8 @@ int ipa_hough_dims(int width, int height, double rho, double theta, int* numangl
 size_t ipa_hough_workspace_bytes(int width, int height, int batch, int max_points);
 int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
                        int width, int height, int batch, double rho, double theta,
-                       int32_t* accum, size_t accum_stride, int max_points, int32_t* point_counts,
+                       int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                       int max_points, int32_t* point_counts,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* Local maxima of the accumulator above `threshold` (the findLocalMaximums step
@@ -219,8 +229,11 @@ int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
  * 64-bit keys (votes << 32 | (0xFFFFFFFF - accumulator index)), in no particular
  * order; sorting them in DESCENDING order yields cv2's line order.
  * peak_counts[b] receives the number found (may exceed capacity: then only the
- * first `capacity` were kept and the caller retries). */
-int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle, int numrho, int batch,
+ * first `capacity` were kept and the caller retries).  `seg_max` = the array
+ * ipa_hough_accum_u8 / ipa_front_end_u8 filled for these accumulators, or NULL
+ * (then every cell is read). */
+int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, const int32_t* seg_max,
+                        int numangle, int numrho, int batch,
                         int threshold, uint64_t* keys, int capacity, int32_t* peak_counts, void* stream);
 
 /* ---- fused front-end ---------------------------------------------------- */
@@ -238,14 +251,16 @@ int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, int numangle,
  *   vlines = morphologyEx(thresh, OPEN, rect(1, vert_len), iterations)
  *   hlines = morphologyEx(thresh, OPEN, rect(horiz_len, 1), iterations)
  *   edges  = Canny(blur5x5 ? GaussianBlur(gray,(5,5),0) : gray, canny_lo, canny_hi)
- *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL)
+ *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL;
+ *            seg_max as for ipa_hough_accum_u8, may be NULL)
  * The five output planes share one pitch/stride.  Synchronises `stream` only
  * where ipa_canny_u8 does. */
 size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points);
 int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
                      uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,
                      size_t plane_pitch, size_t plane_stride,
-                     int32_t* accum, size_t accum_stride, int max_points, int32_t* point_counts,
+                     int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                     int max_points, int32_t* point_counts,
                      int width, int height, int batch,
                      int thresh_val, int vert_len, int horiz_len, int iterations,
                      double canny_lo, double canny_hi, int blur5x5,
