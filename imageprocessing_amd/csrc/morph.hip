@@ -236,6 +236,27 @@ __device__ __forceinline__ void expand16(u32 hbits, u32 value, u8* out)
     *(uint4*)out = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Bits -> bytes through a 256-entry table in LDS (8 result bytes per byte of bits): two table
+// reads and one 16-byte store per 16 pixels, instead of shifts, masks and 32-bit multiplies.
+// The table holds 0x00 / 0xff bytes; `vmask` (the output value in all four bytes) is applied
+// after the lookup.  Built by the first 256 threads of the workgroup (which must have at least
+// that many); ends with a barrier.
+__device__ __forceinline__ void build_expand_lut(uint2* lut)
+{
+    const u32 i = threadIdx.y * blockDim.x + threadIdx.x;
+    if (i < 256) {
+        const u32 lo = (((i & 15u) * 0x00204081u) & 0x01010101u) * 255u;
+        const u32 hi = (((i >> 4) * 0x00204081u) & 0x01010101u) * 255u;
+        lut[i] = make_uint2(lo, hi);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void expand16_lut(const uint2* lut, u32 hbits, u32 vmask, u8* out)
+{
+    const uint2 e0 = lut[hbits & 0xffu], e1 = lut[(hbits >> 8) & 0xffu];
+    *(uint4*)out = make_uint4(e0.x & vmask, e0.y & vmask, e1.x & vmask, e1.y & vmask);
+}
+
 struct Win3 {
     u32 a0, a1, a2;  // 96 consecutive pixels: a0 = lowest x
 };
@@ -278,28 +299,39 @@ __device__ __forceinline__ Win3 comb3(Win3 a, Win3 b, bool dil)
 // kernel of the parsers).  One lane = one 32-pixel word of 4 consecutive rows; it holds
 // words j-1, j, j+1 of a row in registers, runs the doubling steps there and stores the
 // 32 result bytes.
+// NOPS / KX / AX are compile-time copies of nops / kx / ax for the common shapes (0 = use the
+// run-time arguments): every shift becomes an immediate and the loops unroll.
+template <int NOPS, int KX, int AX>
 __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
-                                                     int w, int h, int first_is_dilate, int nops, int kx, int ax,
-                                                     int px, u32 value, const int32_t* __restrict__ value_dev)
+                                                     int w, int h, int first_is_dilate, int nops_rt, int kx_rt, int ax_rt,
+                                                     int px_rt, u32 value, const int32_t* __restrict__ value_dev)
 {
+    __shared__ uint2 lut[256];
+    build_expand_lut(lut);
+    const int nops = NOPS ? NOPS : nops_rt, kx = NOPS ? KX : kx_rt, ax = NOPS ? AX : ax_rt;
+    int px = px_rt;
+    if (NOPS) {
+        px = 1;
+        while (px * 2 <= KX) px *= 2;
+    }
     const int words = (w + 31) >> 5;
     const int j = blockIdx.x * 64 + threadIdx.x;
     const int b = blockIdx.z;
     const int y0 = (blockIdx.y * 4 + threadIdx.y) * ROWS_PER_LANE;
-    if (j >= words) return;
+    const bool live = j < words;  // idle lanes stay: the stores below are rearranged across the wave
     // in-image masks of the three words
     Win3 m;
     m.a0 = j >= 1 ? 0xffffffffu : 0u;
     int rem = w - 32 * j;
     m.a1 = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
     m.a2 = rem - 32 >= 32 ? 0xffffffffu : (rem - 32 > 0 ? ((1u << (rem - 32)) - 1u) : 0u);
-    const u32 val = value_dev ? (u32)value_dev[b] : value;
+    const u32 vmask = (value_dev ? (u32)value_dev[b] : value) * 0x01010101u;
     Win3 in[ROWS_PER_LANE];
 #pragma unroll
     for (int i = 0; i < ROWS_PER_LANE; i++) {
         const int y = y0 + i;
         in[i].a0 = in[i].a1 = in[i].a2 = 0;
-        if (y < h) {
+        if (y < h && live) {
             const u32* row = bits + (size_t)b * bsw + (size_t)y * bpw;
             in[i].a0 = j >= 1 ? row[j - 1] : 0u;
             in[i].a1 = row[j];
@@ -309,22 +341,34 @@ __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bit
 #pragma unroll
     for (int i = 0; i < ROWS_PER_LANE; i++) {
         const int y = y0 + i;
-        if (y >= h) break;
+        if (y >= h) break;  // uniform over the wave (one row per wave and i)
         Win3 v = in[i];
         bool dil = first_is_dilate != 0;
-        for (int stage = 0; stage < nops; stage++) {
+#pragma unroll
+        for (int stage = 0; stage < (NOPS ? NOPS : 2); stage++) {
+            if (stage >= nops) break;
             const u32 ident = dil ? 0u : 0xffffffffu;
             // pixels outside the image take the identity of this stage
             v.a0 = (v.a0 & m.a0) | (ident & ~m.a0);
             v.a1 = (v.a1 & m.a1) | (ident & ~m.a1);
             v.a2 = (v.a2 & m.a2) | (ident & ~m.a2);
-            for (int mm = 1; mm < px; mm <<= 1) v = comb3(v, look_right(v, mm, ident), dil);
+#pragma unroll
+            for (int mm = 1; mm < 32; mm <<= 1)
+                if (mm < px) v = comb3(v, look_right(v, mm, ident), dil);
             v = comb3(look(v, -ax, ident), look(v, kx - px - ax, ident), dil);
             dil = !dil;
         }
-        u8* o = dst.row(b, y) + (size_t)j * 32;
-        expand16(v.a1 & 0xffffu, val, o);
-        if (rem > 16) expand16(v.a1 >> 16, val, o + 16);
+        // The wave's 64 words are 2 KiB of output.  Lane L stores 16-byte piece L of the first
+        // KiB and piece L of the second, so that each store instruction writes 1 KiB without
+        // gaps (32 bytes per lane would leave every instruction half of each cache line).
+        const int lane = threadIdx.x;
+        const u32 r1 = v.a1 & m.a1;
+        const u32 wa = (u32)__shfl((int)r1, lane >> 1), wb = (u32)__shfl((int)r1, 32 + (lane >> 1));
+        const int sh = (lane & 1) * 16;
+        const int xa = blockIdx.x * 2048 + lane * 16, xb = xa + 1024;  // first pixel of each piece
+        u8* orow = dst.row(b, y);
+        if (xa < w) expand16_lut(lut, (wa >> sh) & 0xffffu, vmask, orow + xa);
+        if (xb < w) expand16_lut(lut, (wb >> sh) & 0xffffu, vmask, orow + xb);
     }
 }
 
@@ -362,73 +406,80 @@ __device__ __forceinline__ u32 run_update(u32 (&d)[NS], u32 in, int k)
 template <int NS>
 __global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
                                                     int w, int h, int words, int strips, int strip_rows,
-                                                    long long total, int first_is_dilate, int nops, int ky, int ay,
+                                                    int first_is_dilate, int nops, int ky, int ay,
                                                     u32 value, const int32_t* __restrict__ value_dev)
 {
-    const long long step = (long long)gridDim.x * blockDim.x;
+    __shared__ uint2 lut[256];
+    build_expand_lut(lut);
+    // wave = 64 consecutive word columns of one strip of one image
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + lane;
+    const int sidx = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (sidx >= strips) return;
+    const bool live = j < words;  // idle lanes stay: the stores are rearranged across the wave
     const int below = ky - 1 - ay;  // rows a window reaches below its output row
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
-        const int j = (int)(c % words);
-        long long t = c / words;
-        const int sidx = (int)(t % strips), b = (int)(t / strips);
-        const int r0 = sidx * strip_rows, r1 = min(r0 + strip_rows, h);
-        const u32* col = bits + (size_t)b * bsw + j;
-        const int rem = w - 32 * j;
-        const u32 wmask = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-        const u32 val = value_dev ? (u32)value_dev[b] : value;
-        const bool dil0 = first_is_dilate != 0;
-        u32 d1[NS], d2[NS];
+    const int r0 = sidx * strip_rows, r1 = min(r0 + strip_rows, h);
+    const u32* col = bits + (size_t)b * bsw + j;
+    const int rem = w - 32 * j;
+    const u32 wmask = rem >= 32 ? 0xffffffffu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+    const u32 vmask = (value_dev ? (u32)value_dev[b] : value) * 0x01010101u;
+    const bool dil0 = first_is_dilate != 0;
+    // Lane L stores 16-byte piece L of the first KiB of the wave's 2 KiB row segment and piece L
+    // of the second: every store instruction then writes 1 KiB without gaps.
+    const int sh = (lane & 1) * 16;
+    const int xa = blockIdx.x * 2048 + lane * 16, xb = xa + 1024;
+    u32 d1[NS], d2[NS];
 #pragma unroll
-        for (int i = 0; i < NS; i++) {
-            d1[i] = ((ky >> i) & 1) ? 0xffffffffu : 0u;  // "no row seen yet"
-            d2[i] = d1[i];
+    for (int i = 0; i < NS; i++) {
+        d1[i] = ((ky >> i) & 1) ? 0xffffffffu : 0u;  // "no row seen yet"
+        d2[i] = d1[i];
+    }
+    // stage-1 value for row c1 is known once input row c1 + below has been read; stage-2
+    // (if any) for row r once stage-1 row r + below is known.
+    const int lag1 = below, lag2 = nops == 2 ? below : 0;
+    const int y_first = r0 - nops * ay, y_last = r1 - 1 + lag1 + lag2;
+    auto step = [&](int y, u32 raw) {  // y is the same in all lanes
+        // stage 1 input: image row, or the stage's identity outside the image
+        // (erode: ones; dilate, run as erosion of the complement: also ones)
+        u32 in1 = 0xffffffffu;
+        if (y >= 0 && y < h) in1 = ((dil0 ? ~raw : raw) & wmask) | ~wmask;
+        u32 full1 = run_update<NS>(d1, in1, ky);
+        const int c1 = y - lag1;
+        if (c1 < r0 - (nops == 2 ? ay : 0)) return;
+        u32 s1 = dil0 ? ~full1 : full1;  // stage-1 result for row c1
+        u32 out;
+        int r;
+        if (nops == 1) {
+            out = s1;
+            r = c1;
+        } else {
+            // stage 2 runs the opposite operation on the stage-1 rows; outside the image
+            // its input is its own identity
+            const bool dil1 = !dil0;
+            u32 in2 = 0xffffffffu;
+            if (c1 >= 0 && c1 < h) in2 = ((dil1 ? ~s1 : s1) & wmask) | ~wmask;
+            u32 full2 = run_update<NS>(d2, in2, ky);
+            out = dil1 ? ~full2 : full2;
+            r = c1 - lag2;
         }
-        // stage-1 value for row c1 is known once input row c1 + below has been read; stage-2
-        // (if any) for row r once stage-1 row r + below is known.
-        const int lag1 = below, lag2 = nops == 2 ? below : 0;
-        const int y_first = r0 - nops * ay, y_last = r1 - 1 + lag1 + lag2;
-        auto step = [&](int y, u32 raw) {
-            // stage 1 input: image row, or the stage's identity outside the image
-            // (erode: ones; dilate, run as erosion of the complement: also ones)
-            u32 in1 = 0xffffffffu;
-            if (y >= 0 && y < h) in1 = ((dil0 ? ~raw : raw) & wmask) | ~wmask;
-            u32 full1 = run_update<NS>(d1, in1, ky);
-            const int c1 = y - lag1;
-            if (c1 < r0 - (nops == 2 ? ay : 0)) return;
-            u32 s1 = dil0 ? ~full1 : full1;  // stage-1 result for row c1
-            u32 out;
-            int r;
-            if (nops == 1) {
-                out = s1;
-                r = c1;
-            } else {
-                // stage 2 runs the opposite operation on the stage-1 rows; outside the image
-                // its input is its own identity
-                const bool dil1 = !dil0;
-                u32 in2 = 0xffffffffu;
-                if (c1 >= 0 && c1 < h) in2 = ((dil1 ? ~s1 : s1) & wmask) | ~wmask;
-                u32 full2 = run_update<NS>(d2, in2, ky);
-                out = dil1 ? ~full2 : full2;
-                r = c1 - lag2;
-            }
-            if (r < r0 || r >= r1) return;
-            u8* o = dst.row(b, r) + (size_t)j * 32;
-            out &= wmask;
-            expand16(out & 0xffffu, val, o);
-            if (rem > 16) expand16(out >> 16, val, o + 16);
-        };
-        // four rows per trip: their loads are all in flight before the first is consumed
-        for (int y = y_first; y <= y_last; y += 4) {
-            u32 raw[4];
+        if (r < r0 || r >= r1) return;
+        out &= wmask;
+        const u32 wa = (u32)__shfl((int)out, lane >> 1), wb = (u32)__shfl((int)out, 32 + (lane >> 1));
+        u8* orow = dst.row(b, r);
+        if (xa < w) expand16_lut(lut, (wa >> sh) & 0xffffu, vmask, orow + xa);
+        if (xb < w) expand16_lut(lut, (wb >> sh) & 0xffffu, vmask, orow + xb);
+    };
+    // four rows per trip: their loads are all in flight before the first is consumed
+    for (int y = y_first; y <= y_last; y += 4) {
+        u32 raw[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int yy = y + k;
-                raw[k] = (yy >= 0 && yy < h && yy <= y_last) ? col[(size_t)yy * bpw] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (y + k <= y_last) step(y + k, raw[k]);
+        for (int k = 0; k < 4; k++) {
+            const int yy = y + k;
+            raw[k] = (live && yy >= 0 && yy < h && yy <= y_last) ? col[(size_t)yy * bpw] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (y + k <= y_last) step(y + k, raw[k]);
     }
 }
 
@@ -578,9 +629,18 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
             const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
             Plane db = dst;
             db.p += (size_t)b0 * dst.stride;
-            hipLaunchKernelGGL(k_bitmorph_h3, rows_grid(words, h, nb), rows_block(), 0, st, bits + (size_t)b0 * bsw, bpw, bsw,
-                               db, w, h, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value,
-                               value_dev ? value_dev + b0 : nullptr);
+#define IPA_H3(N, K, A)                                                                                          \
+    hipLaunchKernelGGL((k_bitmorph_h3<N, K, A>), rows_grid(words, h, nb), rows_block(), 0, st, bits + (size_t)b0 * bsw, \
+                       bpw, bsw, db, w, h, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value,                   \
+                       value_dev ? value_dev + b0 : nullptr)
+            // the shapes of the parsers (15-pixel lines, 1 or 2 iterations) and of 3x3 open / close
+            if (nops == 2 && kx == 29 && ax == 14) IPA_H3(2, 29, 14);
+            else if (nops == 2 && kx == 15 && ax == 7) IPA_H3(2, 15, 7);
+            else if (nops == 2 && kx == 3 && ax == 1) IPA_H3(2, 3, 1);
+            else if (nops == 2 && kx == 5 && ax == 2) IPA_H3(2, 5, 2);
+            else if (nops == 1 && kx == 3 && ax == 1) IPA_H3(1, 3, 1);
+            else IPA_H3(0, 0, 0);
+#undef IPA_H3
             IPA_LAUNCH_CHECK();
         }
         return IPA_OK;
@@ -591,15 +651,21 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
         // keep at least ~64k lanes in flight for single images
         while (strip_rows > 16 && (long long)words * cdiv(h, strip_rows) * batch < 65536) strip_rows /= 2;
         const int strips = cdiv(h, strip_rows);
-        const long long total = (long long)words * strips * batch;
-        const dim3 grid(stream_grid(total, 256)), block(256);
-        if (ky < 32)
-            hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, 0, st, bits, bpw, bsw, dst, w, h, words, strips, strip_rows,
-                               total, first_is_dilate, nops, ky, ay, (u32)value, value_dev);
-        else
-            hipLaunchKernelGGL(k_bitmorph_v<8>, grid, block, 0, st, bits, bpw, bsw, dst, w, h, words, strips, strip_rows,
-                               total, first_is_dilate, nops, ky, ay, (u32)value, value_dev);
-        IPA_LAUNCH_CHECK();
+        for (int b0 = 0; b0 < batch; b0 += 65535) {
+            const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            Plane db = dst;
+            db.p += (size_t)b0 * dst.stride;
+            const dim3 grid((unsigned)cdiv(words, 64), (unsigned)cdiv(strips, 4), (unsigned)nb), block(64, 4);
+            if (ky < 32)
+                hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, 0, st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
+                                   strips, strip_rows, first_is_dilate, nops, ky, ay, (u32)value,
+                                   value_dev ? value_dev + b0 : nullptr);
+            else
+                hipLaunchKernelGGL(k_bitmorph_v<8>, grid, block, 0, st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
+                                   strips, strip_rows, first_is_dilate, nops, ky, ay, (u32)value,
+                                   value_dev ? value_dev + b0 : nullptr);
+            IPA_LAUNCH_CHECK();
+        }
         return IPA_OK;
     }
     BitMorphArgs A;
