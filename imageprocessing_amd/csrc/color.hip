@@ -20,6 +20,15 @@ __device__ __forceinline__ u32 luma(u32 b, u32 g, u32 r) { return (b * 3735u + g
 // (48 input bytes).  `cpr` = chunks per row, rounded up to an even number so
 // that lanes 2k / 2k+1 of a wave always hold the two halves of one 32-bit word
 // of the bit plane.
+// Q15 luma of the pixel in the low three bytes of `px` (B, G, R; the top byte is ignored) with
+// two 4-way byte dot products: 3735 = 14*256 + 151, 19235 = 75*256 + 35, 9798 = 38*256 + 70.
+__device__ __forceinline__ u32 luma_dot(u32 px)
+{
+    const u32 hi = __builtin_amdgcn_udot4(px, 0x00264b0eu, 0u, false);
+    const u32 lo = __builtin_amdgcn_udot4(px, 0x00462397u, 16384u, false);
+    return ((hi << 8) + lo) >> 15;
+}
+
 template <bool THRESH, bool PACK>
 __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* __restrict__ bits,
                                                   size_t bpw, size_t bsw, int w, int h, int cpr, int ithresh,
@@ -27,46 +36,64 @@ __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane b
 {
     const int cx = blockIdx.x * 64 + threadIdx.x;
     const int b = blockIdx.z;
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * ROWS_PER_LANE;
+    // a wave's lanes share threadIdx.y: row numbers and row addresses are wave-uniform (scalar)
+    const int y0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * ROWS_PER_LANE;
     const bool live = cx < cpr && cx * 16 < w;
     const bool full = cx * 16 + 16 <= w;
+    const u8* const simg = bgr.p + (size_t)b * bgr.stride;
+    u8* const gimg = gray.p + (size_t)b * gray.stride;
+    u8* const timg = THRESH ? bin.p + (size_t)b * bin.stride : nullptr;
+    const u32 soff = (u32)cx * 48u, doff = (u32)cx * 16u;
     // all loads of the lane's rows are issued before the first is used
     uint4 in[ROWS_PER_LANE][3];
 #pragma unroll
     for (int i = 0; i < ROWS_PER_LANE; i++) {
         const int y = y0 + i;
         if (live && full && y < h) {
-            const uint4* s4 = (const uint4*)(bgr.row(b, y) + (size_t)cx * 48);
+            const uint4* s4 = (const uint4*)(simg + (size_t)y * bgr.pitch + soff);
             in[i][0] = s4[0]; in[i][1] = s4[1]; in[i][2] = s4[2];
         }
     }
+    // thresholded bytes / bit-plane bits as functions of "above the threshold"
+    const u32 a4 = v_above * 0x01010101u, b4 = v_below * 0x01010101u;
+    const u32 nz_a = v_above ? 0xffffu : 0u, nz_b = v_below ? 0xffffu : 0u;
+    u32 rowbits[ROWS_PER_LANE] = {0, 0, 0, 0};  // the lane's 16 bit-plane bits of each row
 #pragma unroll
     for (int i = 0; i < ROWS_PER_LANE; i++) {
         const int y = y0 + i;
-        if (y >= h) break;  // uniform per wave: a wave's lanes share ty
+        if (y >= h) break;  // uniform per wave
         u32 mybits = 0;
         if (live) {
-            u8* gd = gray.row(b, y) + (size_t)cx * 16;
+            u8* gd = gimg + (size_t)y * gray.pitch + doff;
             if (full) {
-                const u32 d[12] = {in[i][0].x, in[i][0].y, in[i][0].z, in[i][0].w, in[i][1].x, in[i][1].y,
-                                   in[i][1].z, in[i][1].w, in[i][2].x, in[i][2].y, in[i][2].z, in[i][2].w};
-                u32 g[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+                const u32 d[13] = {in[i][0].x, in[i][0].y, in[i][0].z, in[i][0].w, in[i][1].x, in[i][1].y, in[i][1].z,
+                                   in[i][1].w, in[i][2].x, in[i][2].y, in[i][2].z, in[i][2].w, 0u};
+                u32 g[4] = {0, 0, 0, 0};
+                u32 above = 0;  // bit k: pixel k is above the threshold
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    u32 v = luma(byte_of(d, 3 * k), byte_of(d, 3 * k + 1), byte_of(d, 3 * k + 2));
+                for (int k = 15; k >= 0; k--) {
+                    const int q = (3 * k) >> 2, sh = (3 * k) & 3;
+                    const u32 px = sh ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh) : d[q];
+                    const u32 v = luma_dot(px);
                     g[k >> 2] |= v << (8 * (k & 3));
-                    if (THRESH) {
-                        bool above = (int)v > ithresh;
-                        t[k >> 2] |= (above ? v_above : v_below) << (8 * (k & 3));
-                        if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << k;
-                    }
+                    if (THRESH) above = (above << 1) | ((u32)(ithresh - (int)v) >> 31);
                 }
                 *(uint4*)gd = make_uint4(g[0], g[1], g[2], g[3]);
-                if (THRESH) *(uint4*)(bin.row(b, y) + (size_t)cx * 16) = make_uint4(t[0], t[1], t[2], t[3]);
+                if (THRESH) {
+                    u32 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const u32 sp = (((above >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;  // bit -> byte
+                        const u32 m = (sp << 8) - sp;                                               // 0x00 / 0xff
+                        t[q] = (m & a4) | (~m & b4);
+                    }
+                    *(uint4*)(timg + (size_t)y * bin.pitch + doff) = make_uint4(t[0], t[1], t[2], t[3]);
+                    if (PACK) mybits = (above & nz_a) | (~above & nz_b);
+                }
             } else {
-                const u8* s = bgr.row(b, y) + (size_t)cx * 48;
+                const u8* s = simg + (size_t)y * bgr.pitch + soff;
                 const int n = w - cx * 16;
-                u8* td = THRESH ? bin.row(b, y) + (size_t)cx * 16 : nullptr;
+                u8* td = THRESH ? timg + (size_t)y * bin.pitch + doff : nullptr;
                 for (int k = 0; k < n; k++) {
                     u32 v = luma(s[3 * k], s[3 * k + 1], s[3 * k + 2]);
                     gd[k] = (u8)v;
@@ -78,11 +105,22 @@ __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane b
                 }
             }
         }
-        if (PACK) {
-            // lanes 2k / 2k+1 hold the two halves of one word of the bit plane (cpr is even)
-            u32 other = __shfl_xor(mybits, 1);
-            if (cx < cpr && !(threadIdx.x & 1)) bits[(size_t)b * bsw + (size_t)y * bpw + (cx >> 1)] = mybits | (other << 16);
-        }
+        if (PACK) rowbits[i] = mybits;
+    }
+    if (PACK) {
+        // The wave's bits of its four rows are 4 x 128 bytes of the bit plane.  They go through
+        // LDS so that ONE store instruction writes them (lane L: the 8 bytes of chunk columns
+        // 4(L%16)..4(L%16)+3 of row L/16) instead of a half-empty store per row.
+        __shared__ unsigned short s_bits[4][ROWS_PER_LANE][64];
+        const int wv = threadIdx.y, lane = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < ROWS_PER_LANE; i++) s_bits[wv][i][lane] = (unsigned short)rowbits[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane >> 4, c0 = (lane & 15) * 4;
+        const uint2 v = *(const uint2*)&s_bits[wv][r][c0];
+        const int yy = y0 + r, cc = blockIdx.x * 64 + c0;
+        if (yy < h && cc < cpr) *(uint2*)((u8*)(bits + (size_t)b * bsw + (size_t)yy * bpw) + (size_t)cc * 2) = v;
     }
 }
 

@@ -133,8 +133,9 @@ struct ProfScope {
 int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bits_pitch_words, size_t bits_stride_words,
                     int w, int h, int batch, int ithresh, int maxval, int inv, hipStream_t st);
 
-// bit-plane geometry: words per row rounded to a multiple of 4 (16 bytes)
-static inline size_t bits_pitch_words(int w) { return align_up((size_t)cdiv(w, 32), 4); }
+// bit-plane geometry: words per row rounded to a multiple of 32 (one 128-byte cache line), so
+// that the 128-byte pieces the producing waves write never share a line between workgroups
+static inline size_t bits_pitch_words(int w) { return align_up((size_t)cdiv(w, 32), 32); }
 
 int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, hipStream_t st);
 int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, int h, int batch, int first_is_dilate,
