@@ -90,6 +90,15 @@ constexpr int ROWS_PER_LANE = 4;
 static inline dim3 rows_block() { return dim3(64, 4, 1); }
 static inline dim3 rows_grid(int cols, int h, int nb) { return dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(h, 4 * ROWS_PER_LANE), (unsigned)nb); }
 
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin by their linear id.
+// This bijection relabels them so that every XCD works on one contiguous range of ids:
+// workgroups that read the same data (consecutive ids) then share one L2.  Speed only.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nwg)
+{
+    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // Bump allocator over the caller's workspace.
 struct Arena {
     u8* base;

@@ -196,6 +196,7 @@ struct VoteArgs {
     int seg_walk;  // 1: each lane walks a contiguous segment of the point list
     int32_t* segmax;  // optional: per image, angle and 512-column segment the largest count
     int nsegs;        // segments per accumulator row
+    int xcd_remap;    // 1: relabel workgroups so that an image's workgroups share an XCD
 };
 
 __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
@@ -344,14 +345,19 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 // unrolled at compile time: cos/sin come straight from the kernel arguments (scalar loads),
 // the LDS byte offset of each angle's row is made wave-uniform with readfirstlane, and one
 // vote costs two packed float instructions (multiply pair, add, add of the rounding constant,
-// each shared by two points) plus one shift-add for the LDS address.
-template <int TG, bool LANE1>
-__global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig T)
+// each shared by two points) plus one shift-add for the LDS address.  NT = threads per
+// workgroup: every workgroup streams the image's whole point list (from L2), so more angles per
+// workgroup mean less list traffic, and 1024 threads keep the CU full with two such workgroups.
+template <int TG, int NT>
+__global__ __launch_bounds__(NT) void k_hough_vote_s(VoteArgs A, Trig T)
 {
     extern __shared__ __align__(16) u32 hist[];
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int grp = blockIdx.x;
+    // all workgroups of one image (they stream the same point list) on one XCD
+    const u32 wg = A.xcd_remap ? xcd_contiguous_id(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y)
+                               : blockIdx.x + blockIdx.y * gridDim.x;
+    const int b = (int)(wg / gridDim.x);
+    const int grp = (int)(wg - (u32)b * gridDim.x);
     const int n0 = grp * TG;
     const int tg = min(TG, A.numangle - n0);
     const int half = (A.numrho - 1) / 2;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
         col0[g] = rmin + half + 1;
         k4[g] = (u32)(half + 1 - col0[g] - 0x4B400000 + g * span) * 4u;
     }
-    for (int i = tid; i < TG * span; i += VOTE_THREADS) hist[i] = 0;
+    for (int i = tid; i < TG * span; i += NT) hist[i] = 0;
     __syncthreads();
 
     const u32 npts = min((u32)A.counts[b], A.cap);
@@ -384,19 +390,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
     const u32 nfull = npts >> 2;
     char* const hb = (char*)hist;
     const f2 magic = {12582912.0f, 12582912.0f};
-    // Four points per lane and trip.  LANE1 = false: four consecutive list entries per lane (one
-    // 16-byte load); LANE1 = true: neighbouring lanes hold neighbouring entries and a lane's
-    // four points are 512 entries apart (four coalesced 4-byte loads).
-    const u32 ntrips = LANE1 ? npts / (4 * VOTE_THREADS) : (nfull + VOTE_THREADS - 1) / VOTE_THREADS;
-    const u32 tail0 = LANE1 ? ntrips * (4 * VOTE_THREADS) : nfull * 4;
-    auto load4 = [&](u32 trip) -> uint4 {
-        if (LANE1) {
-            const u32* q = pts + (size_t)trip * (4 * VOTE_THREADS) + tid;
-            return make_uint4(q[0], q[VOTE_THREADS], q[2 * VOTE_THREADS], q[3 * VOTE_THREADS]);
-        }
-        return pts4[trip * VOTE_THREADS + tid];
-    };
-    auto valid = [&](u32 trip) -> bool { return LANE1 ? trip < ntrips : trip * VOTE_THREADS + tid < nfull; };
+    // four consecutive list entries per lane and trip (one 16-byte load), next trip prefetched
+    const u32 tail0 = nfull * 4;
+    auto load4 = [&](u32 trip) -> uint4 { return pts4[trip * NT + tid]; };
+    auto valid = [&](u32 trip) -> bool { return trip * NT + tid < nfull; };
     u32 i = 0;
     uint4 cur = make_uint4(0, 0, 0, 0);
     if (valid(0)) cur = load4(0);
@@ -423,7 +420,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
         i = inext;
     }
     // the points left over by the four-at-a-time loop
-    for (u32 j = tail0 + tid; j < npts; j += VOTE_THREADS) {
+    for (u32 j = tail0 + tid; j < npts; j += NT) {
         const u32 p = pts[j];
         const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
 #pragma unroll
@@ -438,7 +435,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
         if (g < tg) {
             int32_t* row = acc + (size_t)(n0 + g + 1) * ncols;
             const u32* hg = hist + g * span;
-            for (int col = tid; col < ncols; col += VOTE_THREADS) {
+            for (int col = tid; col < ncols; col += NT) {
                 const int idx = col - col0[g];
                 row[col] = (unsigned)idx < (unsigned)span ? (int32_t)hg[idx] : 0;
             }
@@ -448,7 +445,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
         // largest count of every HOUGH_SEG-column segment of every row: one wave per (row, segment)
         int32_t* sm = A.segmax + ((size_t)b * A.numangle + n0) * A.nsegs;
         const int lane = tid & 63, wave = tid >> 6;
-        for (int q = wave; q < tg * A.nsegs; q += VOTE_THREADS / 64) {
+        for (int q = wave; q < tg * A.nsegs; q += NT / 64) {
             const int g = q / A.nsegs, j = q - g * A.nsegs;
             int c0 = 0;
 #pragma unroll
@@ -466,9 +463,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote_s(VoteArgs A, Trig 
         }
     }
     if (grp == 0)
-        for (int col = tid; col < ncols; col += VOTE_THREADS) acc[col] = 0;
+        for (int col = tid; col < ncols; col += NT) acc[col] = 0;
     if (grp == A.groups - 1)
-        for (int col = tid; col < ncols; col += VOTE_THREADS) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
+        for (int col = tid; col < ncols; col += NT) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
 }
 
 // Four cells per lane and trip (independent loads); the four neighbours are read only for
@@ -731,7 +728,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     static int lds_kb = -1;  // IPA_VOTE_LDS_KB: LDS budget per workgroup
     if (lds_kb < 0) {
         const char* e = getenv("IPA_VOTE_LDS_KB");
-        lds_kb = e ? atoi(e) : 40;
+        lds_kb = e ? atoi(e) : 78;
         if (lds_kb < 8) lds_kb = 8;
         if (lds_kb > 150) lds_kb = 150;
     }
@@ -745,16 +742,23 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         const char* e = getenv("IPA_VOTE_SCALAR");
         scalar_ok = e ? atoi(e) : 1;
     }
-    static int lane1 = -1;  // IPA_VOTE_LANE1=1: neighbouring lanes vote for neighbouring list entries
-    if (lane1 < 0) {
-        const char* e = getenv("IPA_VOTE_LANE1");
-        lane1 = e ? atoi(e) : 0;
+    static int vote_nt = -1;  // IPA_VOTE_THREADS: 512 or 1024 threads per workgroup
+    if (vote_nt < 0) {
+        const char* e = getenv("IPA_VOTE_THREADS");
+        vote_nt = e ? atoi(e) : 1024;
+        if (vote_nt != 512) vote_nt = 1024;
     }
     int tgs = 0;
     if (scalar_ok && !pack16 && !check && !A.seg_walk) tgs = tg >= 8 ? 8 : tg >= 4 ? 4 : tg >= 2 ? 2 : 1;
     if (tgs) tg = tgs;
     A.tg = tg;
     A.groups = cdiv(numangle, tg);
+    static int remap = -1;  // IPA_VOTE_XCD=0 keeps the plain block order
+    if (remap < 0) {
+        const char* e = getenv("IPA_VOTE_XCD");
+        remap = e ? atoi(e) : 0;
+    }
+    A.xcd_remap = remap;
     A.nsegs = hough_segments(numrho);
     A.segmax = tgs ? seg_max : nullptr;
     if (seg_max && !tgs)  // this kernel variant does not produce the maxima: mark every segment as worth reading
@@ -765,14 +769,14 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
     ProfScope ps(PROF_HOUGH_VOTE, st);
@@ -784,22 +788,18 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.accum = accum + (size_t)b0 * accum_stride;
         if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
-        if (tgs == 8 && lane1)
-            hipLaunchKernelGGL((k_hough_vote_s<8, true>), grid, block, lds, st, Ab, T);
-        else if (tgs == 4 && lane1)
-            hipLaunchKernelGGL((k_hough_vote_s<4, true>), grid, block, lds, st, Ab, T);
-        else if (tgs == 2 && lane1)
-            hipLaunchKernelGGL((k_hough_vote_s<2, true>), grid, block, lds, st, Ab, T);
-        else if (tgs == 8)
-            hipLaunchKernelGGL((k_hough_vote_s<8, false>), grid, block, lds, st, Ab, T);
-        else if (tgs == 4)
-            hipLaunchKernelGGL((k_hough_vote_s<4, false>), grid, block, lds, st, Ab, T);
-        else if (tgs == 2)
-            hipLaunchKernelGGL((k_hough_vote_s<2, false>), grid, block, lds, st, Ab, T);
-        else if (tgs == 1 && lane1)
-            hipLaunchKernelGGL((k_hough_vote_s<1, true>), grid, block, lds, st, Ab, T);
-        else if (tgs == 1)
-            hipLaunchKernelGGL((k_hough_vote_s<1, false>), grid, block, lds, st, Ab, T);
+#define IPA_VOTE_S(TGV)                                                                               \
+    do {                                                                                              \
+        if (vote_nt == 1024)                                                                          \
+            hipLaunchKernelGGL((k_hough_vote_s<TGV, 1024>), grid, dim3(1024), lds, st, Ab, T);         \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_hough_vote_s<TGV, 512>), grid, dim3(512), lds, st, Ab, T);           \
+    } while (0)
+        if (tgs == 8) IPA_VOTE_S(8);
+        else if (tgs == 4) IPA_VOTE_S(4);
+        else if (tgs == 2) IPA_VOTE_S(2);
+        else if (tgs == 1) IPA_VOTE_S(1);
+#undef IPA_VOTE_S
         else if (pack16 && !check)
             hipLaunchKernelGGL((k_hough_vote<true, false>), grid, block, lds, st, Ab, T);
         else if (pack16)
