@@ -8,6 +8,7 @@
 #include "common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -91,6 +92,109 @@ __global__ __launch_bounds__(256) void k_gauss_col(const u16* __restrict__ tmp, 
 #pragma unroll
         for (int q = 0; q < 4; q++) o |= min((acc[q] + 32768u) >> 16, 255u) << (8 * q);
         *(u32*)(dst.row(b, y) + qx * 4) = o;
+    }
+}
+
+// ---- streaming 3- and 5-tap Gaussian ------------------------------------------------
+// One wave walks a 256-pixel-wide strip of the image downwards, lane = 4 adjacent pixels, all
+// state in registers (no LDS, no intermediate plane).  Horizontal pass in packed 16-bit
+// (Q8.8, at most 255 * 256), the last five horizontal rows are kept and combined with 32-bit
+// multiply-adds: (sum + 2^15) >> 16, exactly the two fixed-point passes of the generic
+// kernels.  The outermost lanes only feed their neighbours, so a strip yields 248 columns.
+// Taps are symmetric: (k0, k1, k2, k1, k0), k0 = 0 for three taps.
+constexpr int G5_ROWS = 60;  // a multiple of 5, the period of the rolling row registers
+constexpr int G5_COLS = 248;
+
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2v g5_pair(u32 v) { return __builtin_bit_cast(us2v, v); }
+__device__ __forceinline__ u32 g5_u32(us2v v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ u32 g5_from_below(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ u32 g5_from_above(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }
+// acc + (low / high 16 bits of h) * k
+__device__ __forceinline__ u32 g5_mad_lo(u32 h, u32 k, u32 acc)
+{
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(h), "s"(k), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ u32 g5_mad_hi(u32 h, u32 k, u32 acc)
+{
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(h), "s"(k), "v"(acc));
+    return r;
+}
+
+struct G5Row {
+    u32 h01, h23;  // horizontal sums of the lane's 4 pixels (16-bit pairs)
+};
+
+__global__ __launch_bounds__(256) void k_gauss5_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
+                                                       int nwaves, int border, int kx0, int kx1, int kx2, int ky0,
+                                                       int ky1, int ky2)
+{
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 wid = blockIdx.x * 4u + (u32)wv;
+    if (wid >= (u32)nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const u32 t = wid / (u32)strips_x;
+    const int sx = (int)(wid - t * (u32)strips_x);
+    const int b = (int)(t / (u32)bands), band = (int)(t - (u32)b * (u32)bands);
+    const int x = sx * G5_COLS - 4 + 4 * lane;
+    const int y0 = band * G5_ROWS, y1 = min(y0 + G5_ROWS, h);
+    const bool writer = lane >= 1 && lane <= 62 && x < w;
+    // each lane reads one 32-bit word inside the row; byte selectors realise the border rule
+    // while they widen the bytes to 16-bit pairs (columns further than 2 outside never matter)
+    int r4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r4[j] = border_idx(min(max(x + j, -2), w + 1), w, border);
+    const int xc = min(min(min(r4[0], r4[1]), min(r4[2], r4[3])), w - 4);
+    const u32 sel01 = (0x0cu << 24) | ((u32)min(r4[1] - xc, 3) << 16) | (0x0cu << 8) | (u32)min(r4[0] - xc, 3);
+    const u32 sel23 = (0x0cu << 24) | ((u32)min(r4[3] - xc, 3) << 16) | (0x0cu << 8) | (u32)min(r4[2] - xc, 3);
+    const u8* const simg = src.p + (size_t)b * src.stride;
+    u8* const dimg = dst.p + (size_t)b * dst.stride;
+    const u32 spitch = (u32)src.pitch, dpitch = (u32)dst.pitch;
+    auto load_row = [&](int yy) -> u32 {  // yy may lie up to 2 rows outside: same border rule
+        const int ry = border_idx(min(max(yy, -2), h + 1), h, border);
+        return *(const u32*)(simg + (size_t)((u32)ry * spitch + (u32)xc));
+    };
+    const u32 kx0p = (u32)kx0 * 0x00010001u, kx1p = (u32)kx1 * 0x00010001u, kx2p = (u32)kx2 * 0x00010001u;
+    auto hrow = [&](u32 g) -> G5Row {
+        const u32 c0 = __builtin_amdgcn_perm(0, g, sel01), c1 = __builtin_amdgcn_perm(0, g, sel23);  // columns 0,1 / 2,3
+        const u32 L = g5_from_below(c1), R = g5_from_above(c0);                                       // columns -2,-1 / 4,5
+        const u32 m1 = __builtin_amdgcn_alignbit(c0, L, 16), p12 = __builtin_amdgcn_alignbit(c1, c0, 16),
+                  p34 = __builtin_amdgcn_alignbit(R, c1, 16);
+        G5Row o;
+        o.h01 = g5_u32((g5_pair(L) + g5_pair(c1)) * g5_pair(kx0p) + (g5_pair(m1) + g5_pair(p12)) * g5_pair(kx1p) +
+                       g5_pair(c0) * g5_pair(kx2p));
+        o.h23 = g5_u32((g5_pair(c0) + g5_pair(R)) * g5_pair(kx0p) + (g5_pair(p12) + g5_pair(p34)) * g5_pair(kx1p) +
+                       g5_pair(c1) * g5_pair(kx2p));
+        return o;
+    };
+    // horizontal rows y-2 .. y+1 are carried, row y+2 is produced in the trip that outputs row y
+    G5Row ra = hrow(load_row(y0 - 2)), rb = hrow(load_row(y0 - 1)), rc = hrow(load_row(y0)), rd = hrow(load_row(y0 + 1));
+    u32 gq[5];  // five gray rows in flight ahead of the one being consumed
+#pragma unroll
+    for (int k = 0; k < 5; k++) gq[k] = load_row(y0 + 2 + k);
+    const u32 k0 = (u32)ky0, k1 = (u32)ky1, k2 = (u32)ky2;
+#pragma unroll 5
+    for (int it = 0; it < G5_ROWS; it++) {  // fixed trip count: rows past y1 are computed but not stored
+        const int y = y0 + it;
+        const G5Row re = hrow(gq[it % 5]);
+        gq[it % 5] = load_row(y + 7);
+        u32 o[4];
+        {
+            u32 a;
+            a = g5_mad_lo(ra.h01, k0, 32768u); a = g5_mad_lo(re.h01, k0, a); a = g5_mad_lo(rb.h01, k1, a);
+            a = g5_mad_lo(rd.h01, k1, a); o[0] = g5_mad_lo(rc.h01, k2, a) >> 16;
+            a = g5_mad_hi(ra.h01, k0, 32768u); a = g5_mad_hi(re.h01, k0, a); a = g5_mad_hi(rb.h01, k1, a);
+            a = g5_mad_hi(rd.h01, k1, a); o[1] = g5_mad_hi(rc.h01, k2, a) >> 16;
+            a = g5_mad_lo(ra.h23, k0, 32768u); a = g5_mad_lo(re.h23, k0, a); a = g5_mad_lo(rb.h23, k1, a);
+            a = g5_mad_lo(rd.h23, k1, a); o[2] = g5_mad_lo(rc.h23, k2, a) >> 16;
+            a = g5_mad_hi(ra.h23, k0, 32768u); a = g5_mad_hi(re.h23, k0, a); a = g5_mad_hi(rb.h23, k1, a);
+            a = g5_mad_hi(rd.h23, k1, a); o[3] = g5_mad_hi(rc.h23, k2, a) >> 16;
+        }
+        if (writer && y < y1) *(u32*)(dimg + (size_t)((u32)y * dpitch + (u32)x)) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        ra = rb; rb = rc; rc = rd; rd = re;
     }
 }
 
@@ -268,6 +372,26 @@ static int gaussian_impl(Plane s, Plane d, int width, int height, int batch, int
     tx.n = kw; ty.n = kh; tx.border = ty.border = border;
     gaussian_taps_q8(kw, sigma_x > 0 ? sigma_x : 0, tx.q8);
     gaussian_taps_q8(kh, sigma_y > 0 ? sigma_y : 0, ty.q8);
+    // 3 / 5 taps per direction, a border rule that reads inside the image, and an image the
+    // 32-bit offsets and word reads of the streaming kernel can address: no intermediate plane
+    static int g5 = -1;  // IPA_GAUSS_STREAM=0 forces the two-pass kernels
+    if (g5 < 0) {
+        const char* e = getenv("IPA_GAUSS_STREAM");
+        g5 = e ? atoi(e) : 1;
+    }
+    if (g5 && (kw == 3 || kw == 5) && (kh == 3 || kh == 5) && border != 0 && width >= 8 && height >= 2 &&
+        (unsigned long long)height * s.pitch < 0xffffffffull && (unsigned long long)height * d.pitch < 0xffffffffull) {
+        const int strips_x = cdiv(width, G5_COLS), bands = cdiv(height, G5_ROWS);
+        const long long nwaves = (long long)strips_x * bands * batch;
+        IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "GaussianBlur: too many strips");
+        // outer, middle and centre tap of each direction (no outer tap for 3 taps)
+        const int x0 = kw == 3 ? 0 : tx.q8[0], x1 = tx.q8[kw == 3 ? 0 : 1], x2 = tx.q8[kw == 3 ? 1 : 2];
+        const int v0 = kh == 3 ? 0 : ty.q8[0], v1 = ty.q8[kh == 3 ? 0 : 1], v2 = ty.q8[kh == 3 ? 1 : 2];
+        hipLaunchKernelGGL(k_gauss5_stream, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, s, d, width, height, strips_x,
+                           bands, (int)nwaves, border, x0, x1, x2, v0, v1, v2);
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
     Arena ar(ws, ws_bytes);
     size_t tp = tmp_pitch_elems(width);
     u16* tmp = (u16*)ar.take(tp * sizeof(u16) * (size_t)height * batch);

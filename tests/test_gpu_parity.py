@@ -166,6 +166,17 @@ def test_gaussian_borders(border):
     assert np.array_equal(cv2.GaussianBlur(g, (7, 7), 1.3, borderType=border), fr.gaussian_blur(g, (7, 7), 1.3, 0, border))
 
 
+@pytest.mark.parametrize("h,w", [(2, 8), (9, 8), (61, 247), (60, 248), (59, 249), (121, 252), (64, 255), (130, 497), (7, 1000)])
+@pytest.mark.parametrize("ks,sx,border", [((5, 5), 0, 4), ((3, 3), 0, 4), ((5, 3), 1.0, 1), ((3, 5), 0.8, 2), ((5, 5), 1.0, 4)])
+def test_gaussian_streaming_kernel_shapes(h, w, ks, sx, border):
+    # 3- and 5-tap blurs run in the register-streaming kernel: strip (248 columns) and band
+    # (60 rows) boundaries, every border rule that reads inside the image, mixed tap counts
+    g = rand_gray(h * 7 + w, h, w)
+    a = cv2.GaussianBlur(g, ks, sx, borderType=border)
+    b = fr.gaussian_blur(g, ks, sx, 0, border)
+    assert np.array_equal(a, b), int((a != b).sum())
+
+
 # ------------------------------------------------------------------ morphology
 MORPH_CASES = [((3, 3), 1), ((3, 3), 2), ((15, 1), 2), ((1, 15), 2), ((2, 2), 1), ((4, 3), 2), ((1, 1), 3), ((5, 7), 0),
                ((30, 1), 1), ((1, 30), 1), ((101, 1), 2), ((1, 101), 2), ((33, 1), 1), ((1, 64), 1)]
