@@ -22,58 +22,134 @@ namespace {
 
 // 8-bit plane -> bit plane (bit = pixel != 0), plus the largest pixel value of
 // each image (the common non-zero value when the image is two-valued).
-__global__ __launch_bounds__(256) void k_pack_bits(Plane src, u32* __restrict__ bits, size_t bpw, size_t bsw, int w,
-                                                   int h, int cpr, long long total, int32_t* __restrict__ vmax)
+// bit 0 of each byte of x -> 4 adjacent bits
+__device__ __forceinline__ u32 pb_bytes_to_bits(u32 x) { return ((x & 0x01010101u) * 0x10204080u) >> 28; }
+// 1 in bit 0 of every non-zero byte
+__device__ __forceinline__ u32 pb_nonzero_bytes(u32 v) { return ((v | ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; }
+// per-byte maximum of two dwords, through the even / odd bytes as 16-bit pairs
+__device__ __forceinline__ u32 pb_max_bytes(u32 a, u32 b)
 {
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < total; base += step) {
-        const long long c = base + threadIdx.x;
-        u32 mybits = 0, mx = 0;
-        int cx = 0, y = 0, b = 0;
-        if (c < total) {
-            cx = (int)(c % cpr);
-            long long t = c / cpr;
-            y = (int)(t % h);
-            b = (int)(t / h);
-            int n = min(16, w - cx * 16);
-            if (n > 0) {
-                uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
-                u32 d[4] = {a.x, a.y, a.z, a.w};
+    typedef unsigned short us2p __attribute__((ext_vector_type(2)));
+    const us2p ae = __builtin_bit_cast(us2p, a & 0x00ff00ffu), be = __builtin_bit_cast(us2p, b & 0x00ff00ffu);
+    const us2p ao = __builtin_bit_cast(us2p, (a >> 8) & 0x00ff00ffu), bo = __builtin_bit_cast(us2p, (b >> 8) & 0x00ff00ffu);
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(ae, be)) | (__builtin_bit_cast(u32, __builtin_elementwise_max(ao, bo)) << 8);
+}
+
+// 8-bit plane -> bit plane ("pixel is non-zero") plus the largest pixel value of each image.
+// Thread (tx, ty) of block (bx, by, bz): 16-pixel chunk column 64 bx + tx of four rows; the
+// wave's bits of its four rows leave through LDS as one 8-byte store per lane, and the
+// maximum costs at most one atomic per workgroup.
+__global__ __launch_bounds__(256) void k_pack_bits(Plane src, u32* __restrict__ bits, size_t bpw, size_t bsw, int w,
+                                                   int h, int cpr, int32_t* __restrict__ vmax)
+{
+    __shared__ unsigned short s_bits[4][ROWS_PER_LANE][64];
+    __shared__ u32 s_max[4];
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int cx = blockIdx.x * 64 + lane;
+    const int b = blockIdx.z;
+    const int y0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(wv)) * ROWS_PER_LANE;
+    const int n = w - cx * 16;  // pixels of the chunk inside the image
+    const u32 keep = n >= 16 ? 0xffffu : (n > 0 ? (1u << n) - 1u : 0u);
+    uint4 a[ROWS_PER_LANE];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    u32 v = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    if (i < n && v) {
-                        mybits |= 1u << i;
-                        mx = max(mx, v);
-                    }
-                }
-            }
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        a[i] = make_uint4(0, 0, 0, 0);
+        if (n > 0 && y0 + i < h) a[i] = *(const uint4*)(src.row(b, y0 + i) + (size_t)cx * 16);
+    }
+    u32 mx4 = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        const u32 m = (pb_bytes_to_bits(pb_nonzero_bytes(a[i].x)) | (pb_bytes_to_bits(pb_nonzero_bytes(a[i].y)) << 4) |
+                       (pb_bytes_to_bits(pb_nonzero_bytes(a[i].z)) << 8) | (pb_bytes_to_bits(pb_nonzero_bytes(a[i].w)) << 12)) & keep;
+        s_bits[wv][i][lane] = (unsigned short)m;
+        if (n >= 16) {
+            mx4 = pb_max_bytes(mx4, pb_max_bytes(pb_max_bytes(a[i].x, a[i].y), pb_max_bytes(a[i].z, a[i].w)));
+        } else if (n > 0) {
+            const u32 d[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+            for (int k = 0; k < n; k++) mx4 = max(mx4, (d[k >> 2] >> (8 * (k & 3))) & 0xffu);
         }
-        u32 other = __shfl_xor(mybits, 1);
-        if (c < total && !(threadIdx.x & 1)) bits[(size_t)b * bsw + (size_t)y * bpw + (cx >> 1)] = mybits | (other << 16);
-        if (mx && (u32)vmax[b] < mx) atomicMax(&vmax[b], (int32_t)mx);
+    }
+    u32 mx = max(max(mx4 & 0xffu, (mx4 >> 8) & 0xffu), max((mx4 >> 16) & 0xffu, mx4 >> 24));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, o));
+    if (lane == 0) s_max[wv] = mx;
+    __syncthreads();  // also orders the s_bits writes before the reads below
+    const int r = lane >> 4, c0 = (lane & 15) * 4;
+    const uint2 v = *(const uint2*)&s_bits[wv][r][c0];
+    const int yy = y0 + r, cc = blockIdx.x * 64 + c0;
+    if (yy < h && cc < cpr) *(uint2*)((u8*)(bits + (size_t)b * bsw + (size_t)yy * bpw) + (size_t)cc * 2) = v;
+    if (lane == 0 && wv == 0) {
+        const u32 bm = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        // a stale read only costs a redundant atomic
+        if (bm && (u32)__builtin_nontemporal_load(&vmax[b]) < bm) atomicMax(&vmax[b], (int32_t)bm);
     }
 }
 
-// Two-valued test: flags[b] = common non-zero value, 0 (all zero) or -1.
-__global__ __launch_bounds__(256) void k_binary_check(Plane src, int w, int h, int cpr, long long total,
-                                                      int32_t* __restrict__ flags)
+__device__ __forceinline__ u32 pb_min_bytes(u32 a, u32 b)
 {
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
-        int cx = (int)(c % cpr);
-        long long t = c / cpr;
-        int y = (int)(t % h), b = (int)(t / h);
-        int n = min(16, w - cx * 16);
-        uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
-        u32 d[4] = {a.x, a.y, a.z, a.w};
-        for (int i = 0; i < n; i++) {
-            int v = (d[i >> 2] >> (8 * (i & 3))) & 0xff;
-            if (!v) continue;
-            int cur = flags[b];
-            if (cur == v || cur == -1) continue;
-            int old = atomicCAS(&flags[b], 0, v);
-            if (old != 0 && old != v) atomicExch(&flags[b], -1);
+    typedef unsigned short us2p __attribute__((ext_vector_type(2)));
+    const us2p ae = __builtin_bit_cast(us2p, a & 0x00ff00ffu), be = __builtin_bit_cast(us2p, b & 0x00ff00ffu);
+    const us2p ao = __builtin_bit_cast(us2p, (a >> 8) & 0x00ff00ffu), bo = __builtin_bit_cast(us2p, (b >> 8) & 0x00ff00ffu);
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(ae, be)) | (__builtin_bit_cast(u32, __builtin_elementwise_min(ao, bo)) << 8);
+}
+
+// flags[b]: 0 = no non-zero pixel seen yet, v = every non-zero pixel so far equals v, -1 = two
+// different non-zero values.  Each workgroup reduces the smallest and largest non-zero pixel
+// of its 1024 x 16 pixels and touches the flag at most twice.
+__global__ __launch_bounds__(256) void k_binary_check(Plane src, int w, int h, int cpr, int32_t* __restrict__ flags)
+{
+    __shared__ u32 s_mm[4][2];
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int cx = blockIdx.x * 64 + lane;
+    const int b = blockIdx.z;
+    const int y0 = ((int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(wv)) * ROWS_PER_LANE;
+    const int n = w - cx * 16;
+    u32 mx = 0, mn = 255;
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; i++) {
+        if (n <= 0 || y0 + i >= h) continue;
+        const uint4 a = *(const uint4*)(src.row(b, y0 + i) + (size_t)cx * 16);
+        if (n >= 16) {
+            const u32 d[4] = {a.x, a.y, a.z, a.w};
+            u32 hi = 0, lo = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                hi = pb_max_bytes(hi, d[q]);
+                lo = pb_min_bytes(lo, d[q] | ((pb_nonzero_bytes(d[q]) ^ 0x01010101u) * 255u));  // zero bytes -> 0xff
+            }
+            mx = max(mx, max(max(hi & 0xffu, (hi >> 8) & 0xffu), max((hi >> 16) & 0xffu, hi >> 24)));
+            mn = min(mn, min(min(lo & 0xffu, (lo >> 8) & 0xffu), min((lo >> 16) & 0xffu, lo >> 24)));
+        } else {
+            const u32 d[4] = {a.x, a.y, a.z, a.w};
+            for (int k = 0; k < n; k++) {
+                const u32 v = (d[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                if (v) {
+                    mx = max(mx, v);
+                    mn = min(mn, v);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        mx = max(mx, (u32)__shfl_xor((int)mx, o));
+        mn = min(mn, (u32)__shfl_xor((int)mn, o));
+    }
+    if (lane == 0) {
+        s_mm[wv][0] = mx;
+        s_mm[wv][1] = mn;
+    }
+    __syncthreads();
+    if (lane == 0 && wv == 0) {
+        const u32 bmx = max(max(s_mm[0][0], s_mm[1][0]), max(s_mm[2][0], s_mm[3][0]));
+        const u32 bmn = min(min(s_mm[0][1], s_mm[1][1]), min(s_mm[2][1], s_mm[3][1]));
+        if (bmx) {
+            if (bmn != bmx) {
+                atomicExch(&flags[b], -1);
+            } else {
+                const int old = atomicCAS(&flags[b], 0, (int)bmx);
+                if (old != 0 && old != (int)bmx) atomicExch(&flags[b], -1);
+            }
         }
     }
 }
@@ -605,11 +681,15 @@ int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h,
 {
     int cpr = cdiv(w, 16);
     cpr += cpr & 1;
-    long long total = (long long)cpr * h * batch;
     IPA_HIP(hipMemsetAsync(vmax, 0, sizeof(int32_t) * (size_t)batch, st));
-    hipLaunchKernelGGL(k_pack_bits, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, bits, bpw, bsw, w, h, cpr,
-                       total, vmax);
-    IPA_LAUNCH_CHECK();
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        Plane sb = src;
+        sb.p += (size_t)b0 * src.stride;
+        hipLaunchKernelGGL(k_pack_bits, rows_grid(cpr, h, nb), rows_block(), 0, st, sb, bits + (size_t)b0 * bsw, bpw, bsw, w, h,
+                           cpr, vmax + b0);
+        IPA_LAUNCH_CHECK();
+    }
     return IPA_OK;
 }
 
@@ -778,11 +858,15 @@ IPA_EXPORT int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t 
     Plane s = mkplane(src, src_pitch, src_stride);
     IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
                 "binary_check: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
-    int cpr = cdiv(width, 16);
-    long long total = (long long)cpr * height * batch;
-    hipLaunchKernelGGL(k_binary_check, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s, width,
-                       height, cpr, total, flags);
-    IPA_LAUNCH_CHECK();
+    const int cpr = cdiv(width, 16);
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        Plane sb = s;
+        sb.p += (size_t)b0 * s.stride;
+        hipLaunchKernelGGL(k_binary_check, rows_grid(cpr, height, nb), rows_block(), 0, (hipStream_t)stream, sb, width, height,
+                           cpr, flags + b0);
+        IPA_LAUNCH_CHECK();
+    }
     return IPA_OK;
 }
 
