@@ -293,6 +293,182 @@ __global__ __launch_bounds__(256) void k_adapt_col(Plane src, const u32* __restr
     }
 }
 
+// ---- streaming adaptive threshold ---------------------------------------------------------
+// One wave walks a 256-pixel-wide strip downwards, lane = 4 adjacent pixels.  A lane reads its
+// own row window [x - R, x + 3 + R] (clamped: BORDER_REPLICATE) straight from memory, so no
+// data moves between lanes; the row-pass results of the last 2R + 1 rows live in a ring in
+// LDS that is private to the lane's columns (no barrier, no intermediate plane).  The float
+// path keeps the operation order of the two-pass kernels: taps accumulated left to right in
+// the row pass, symmetric pairs in the column pass, every multiply and add rounded on its own.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 adapt_load_dword(const u8* row, int xk, int w)
+{
+    if (xk >= 0 && xk + 4 <= w) return *(const u32*)(row + xk);
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (u32)row[min(max(xk + j, 0), w - 1)] << (8 * j);
+    return v;
+}
+
+template <int R, bool GAUSS>
+__global__ __launch_bounds__(256) void k_adapt_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
+                                                      int band_rows, int nwaves, TapsF T, double box_scale, int idelta,
+                                                      int inv, u32 maxv)
+{
+    constexpr int N = 2 * R + 1;           // taps
+    constexpr int PAD = (R + 3) / 4 * 4;   // window start x - PAD, a multiple of 4 pixels
+    constexpr int ND = (PAD + 4 + R + 3) / 4;  // dwords covering [x - PAD, x + 3 + R]
+    // ring rows: exactly N for small windows (LDS, hence occupancy, matters more than index
+    // arithmetic there), else a power of two so that a slot is a mask away
+    constexpr int SLOTS = N <= 16 ? N : (N <= 32 ? 32 : 64);
+    constexpr bool POW2 = (SLOTS & (SLOTS - 1)) == 0;
+    extern __shared__ __align__(16) u32 ring[];  // [4 waves][SLOTS rows][64 lanes][4]
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 wid = blockIdx.x * 4u + (u32)wv;
+    if (wid >= (u32)nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const u32 t = wid / (u32)strips_x;
+    const int sx = (int)(wid - t * (u32)strips_x);
+    const int b = (int)(t / (u32)bands), band = (int)(t - (u32)b * (u32)bands);
+    const int x = sx * 256 + 4 * lane;
+    const int y0 = band * band_rows, y1 = min(y0 + band_rows, h);
+    uint4* const myring = (uint4*)ring + (size_t)wv * SLOTS * 64 + lane;  // slot s at myring[s * 64]
+    // Row r (r may lie outside the image: then it holds a copy of the nearest image row, which is
+    // BORDER_REPLICATE) lives in slot (r + 64) & (SLOTS - 1); the column pass never clamps.
+    auto slot = [&](int r) -> uint4* {
+        const int s = POW2 ? ((r + 64) & (SLOTS - 1)) : (r + 64 * SLOTS) % SLOTS;  // r >= -R > -64
+        return myring + s * 64;
+    };
+    // slot of row base + j for 0 <= j < SLOTS, given sb = slot index of row `base`
+    auto slot_rel = [&](int sb, int j) -> uint4* {
+        int s = sb + j;
+        if (POW2) s &= SLOTS - 1;
+        else if (s >= SLOTS) s -= SLOTS;
+        return myring + s * 64;
+    };
+    const bool live = x < w;
+
+    // strips whose windows lie inside the row read plain dwords (wave-uniform choice)
+    const bool interior = sx * 256 - PAD >= 0 && sx * 256 + 252 - PAD + 4 * ND <= w;
+    auto load_row = [&](int yy, u32 (&d)[ND]) {
+        const u8* row = src.row(b, yy);
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < ND; k++) d[k] = *(const u32*)(row + (x - PAD + 4 * k));
+        } else {
+#pragma unroll
+            for (int k = 0; k < ND; k++) d[k] = live ? adapt_load_dword(row, x - PAD + 4 * k, w) : 0u;
+        }
+    };
+    // row pass of one image row (window dwords `d`)
+    auto row_pass = [&](const u32 (&d)[ND]) -> uint4 {
+        uint4 out;
+        if (GAUSS) {
+            float p[N + 3];
+#pragma unroll
+            for (int j = 0; j < N + 3; j++) {
+                const int o = PAD - R + j;  // byte offset inside d
+                p[j] = (float)((d[o >> 2] >> (8 * (o & 3))) & 0xffu);
+            }
+            f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const float k = T.f[i];
+                const f2v p01 = {p[i], p[i + 1]}, p23 = {p[i + 2], p[i + 3]};
+                a01 = a01 + p01 * k;  // -ffp-contract=off: separate multiply and add
+                a23 = a23 + p23 * k;
+            }
+            out = make_uint4(__float_as_uint(a01.x), __float_as_uint(a01.y), __float_as_uint(a23.x), __float_as_uint(a23.y));
+        } else {
+            u32 sacc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < N + 3; j++) {
+                const int o = PAD - R + j;
+                const u32 pv = (d[o >> 2] >> (8 * (o & 3))) & 0xffu;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (j >= q && j < N + q) sacc[q] += pv;
+            }
+            out = make_uint4(sacc[0], sacc[1], sacc[2], sacc[3]);
+        }
+        return out;
+    };
+
+    uint4 last = make_uint4(0, 0, 0, 0);
+    int sb = 0;
+    for (int r = y0 - R, have = -1; r <= y0 + R; r++) {
+        const int rr = min(max(r, 0), h - 1);
+        if (rr != have) {
+            u32 d[ND];
+            load_row(rr, d);
+            last = row_pass(d);
+            have = rr;
+        }
+        *slot(r) = last;
+    }
+    // the window of the row pushed in the next trip is loaded one trip ahead
+    u32 dn[ND];
+    load_row(min(y0 + 1 + R, h - 1), dn);
+    for (int y = y0; y < y1; y++) {
+        if (y > y0) {
+            u32 dc[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) dc[k] = dn[k];
+            load_row(min(y + 1 + R, h - 1), dn);
+            if (y + R <= h - 1) last = row_pass(dc);
+            *slot(y + R) = last;
+        }
+        // slot index of row y - R, advanced by one per trip
+        sb = y == y0 ? (POW2 ? ((y - R + 64) & (SLOTS - 1)) : (y - R + 64 * SLOTS) % SLOTS) : (sb + 1 == SLOTS ? 0 : sb + 1);
+        int mean[4];
+        if (GAUSS) {
+            const uint4 c = *slot_rel(sb, R);
+            const float kc = T.f[R];
+            f2v a01 = {__uint_as_float(c.x) * kc, __uint_as_float(c.y) * kc};
+            f2v a23 = {__uint_as_float(c.z) * kc, __uint_as_float(c.w) * kc};
+#pragma unroll
+            for (int i = 1; i <= R; i++) {
+                const uint4 lo = *slot_rel(sb, R - i), hi = *slot_rel(sb, R + i);
+                const float k = T.f[R + i];
+                const f2v s01 = {__uint_as_float(hi.x) + __uint_as_float(lo.x), __uint_as_float(hi.y) + __uint_as_float(lo.y)};
+                const f2v s23 = {__uint_as_float(hi.z) + __uint_as_float(lo.z), __uint_as_float(hi.w) + __uint_as_float(lo.w)};
+                a01 = a01 + s01 * k;
+                a23 = a23 + s23 * k;
+            }
+            const float av[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int v = __float2int_rn(av[q]);
+                mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+        } else {
+            u32 acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = -R; i <= R; i++) {
+                const uint4 a = *slot_rel(sb, R + i);
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int v = (int)rint((double)acc[q] * box_scale);
+                mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+        }
+        if (live) {
+            const u32 sv = adapt_load_dword(src.row(b, y), x, w);
+            u32 o = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int dlt = (int)((sv >> (8 * q)) & 0xffu) - mean[q];
+                const bool on = inv ? (dlt <= -idelta) : (dlt > -idelta);
+                o |= (on ? maxv : 0u) << (8 * q);
+            }
+            *(u32*)(dst.row(b, y) + x) = o;  // bytes past the width stay inside the pitch
+        }
+    }
+}
+
 // ---- host-side tap tables (cv::getGaussianKernel and its Q0.8 form) ---------
 void gaussian_taps_f64(int n, double sigma, double* k)
 {
@@ -463,15 +639,52 @@ IPA_EXPORT int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, s
     double kd[IPA_MAX_TAPS + 1];
     gaussian_taps_f64(block_size, 0.0, kd);
     for (int i = 0; i < block_size; i++) T.f[i] = (float)kd[i];
+    long mvl = lrint(max_value);
+    u32 maxv = (u32)(mvl < 0 ? 0 : (mvl > 255 ? 255 : mvl));
+    int idelta = type == 0 ? (int)ceil(c) : (int)floor(c);
+    double box_scale = 1.0 / ((double)block_size * block_size);
+    // block sizes of the reference's callers (11, 31) and the small ones: streaming kernel
+    static int astream = -1;  // IPA_ADAPT_STREAM=0 forces the two-pass kernels
+    if (astream < 0) {
+        const char* e = getenv("IPA_ADAPT_STREAM");
+        astream = e ? atoi(e) : 1;
+    }
+    const int R = block_size / 2;
+    if (astream && (R == 1 || R == 2 || R == 3 || R == 5 || R == 15)) {
+        const int band_rows = R <= 5 ? 64 : 128;
+        const int strips_x = cdiv(width, 256), bands = cdiv(height, band_rows);
+        const long long nwaves = (long long)strips_x * bands * batch;
+        IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "adaptiveThreshold: too many strips");
+        const size_t lds = (size_t)4 * (block_size <= 16 ? block_size : 32) * 64 * 16;  // ring slots: see the kernel
+        const dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+#define IPA_ADAPT(RR)                                                                                                    \
+    do {                                                                                                                 \
+        if (method == 1) {                                                                                               \
+            IPA_HIP(hipFuncSetAttribute((const void*)k_adapt_stream<RR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                      \
+            hipLaunchKernelGGL((k_adapt_stream<RR, true>), grid, block, lds, st, s, d, width, height, strips_x, bands,    \
+                               band_rows, (int)nwaves, T, box_scale, idelta, type, maxv);                                \
+        } else {                                                                                                         \
+            IPA_HIP(hipFuncSetAttribute((const void*)k_adapt_stream<RR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                      \
+            hipLaunchKernelGGL((k_adapt_stream<RR, false>), grid, block, lds, st, s, d, width, height, strips_x, bands,   \
+                               band_rows, (int)nwaves, T, box_scale, idelta, type, maxv);                                \
+        }                                                                                                                \
+    } while (0)
+        if (R == 1) IPA_ADAPT(1);
+        else if (R == 2) IPA_ADAPT(2);
+        else if (R == 3) IPA_ADAPT(3);
+        else if (R == 5) IPA_ADAPT(5);
+        else IPA_ADAPT(15);
+#undef IPA_ADAPT
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
     size_t tp = tmp_pitch_elems(width);
     u32* tmp = (u32*)ws;
     int quads = cdiv(width, 4);
     long long total = (long long)quads * height * batch;
     unsigned grid = stream_grid(total, 256);
-    long mvl = lrint(max_value);
-    u32 maxv = (u32)(mvl < 0 ? 0 : (mvl > 255 ? 255 : mvl));
-    int idelta = type == 0 ? (int)ceil(c) : (int)floor(c);
-    double box_scale = 1.0 / ((double)block_size * block_size);
     if (method == 1) {
         hipLaunchKernelGGL((k_adapt_row<true>), dim3(grid), dim3(256), 0, st, s, tmp, tp, tp * (size_t)height, width,
                            height, quads, total, T);

@@ -144,6 +144,18 @@ def test_adaptive_threshold(block, method, typ):
     assert np.array_equal(cv2.adaptiveThreshold(g, 200, 1, 0, 5, -3.5), fr.adaptive_threshold(g, 200, 1, 0, 5, -3.5))
 
 
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 5), (64, 256), (65, 257), (130, 255), (200, 515), (9, 1027)])
+@pytest.mark.parametrize("block,method", [(11, 1), (31, 1), (7, 1), (11, 0), (31, 0), (5, 0), (9, 1), (13, 0)])
+def test_adaptive_threshold_shapes(h, w, block, method):
+    # strip (256 columns) and band (64 / 128 rows) boundaries of the streaming kernel, images
+    # smaller than the window, and block sizes that take the two-pass kernels (9, 13)
+    g = rand_gray(h + 3 * w + block, h, w)
+    for typ in (0, 1):
+        a = cv2.adaptiveThreshold(g, 255, method, typ, block, 2)
+        b = fr.adaptive_threshold(g, 255, method, typ, block, 2)
+        assert np.array_equal(a, b), (typ, int((a != b).sum()))
+
+
 # ------------------------------------------------------------------ blur
 @pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (5, 5), (33, 47), (127, 129), (381, 454)])
 def test_gaussian_5x5_sigma0_exact(h, w):
