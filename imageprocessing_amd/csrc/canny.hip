@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     // wave-uniform values are forced into scalar registers so that the row loop, the row
     // addresses and every "whole wave" decision below run on the scalar unit
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long wave_id = (long long)blockIdx.x * 4 + wv;
+    // neighbouring strips and bands (they share cache lines and halo rows) on one XCD
+    const long long wave_id = (long long)xcd_contiguous_id(blockIdx.x, gridDim.x) * 4 + wv;
     if (wave_id >= nwaves) return;
     const int lane = threadIdx.x & 63;
     u32* pbuf = s_pts[EMIT ? wv : 0];
