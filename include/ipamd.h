@@ -67,7 +67,10 @@ size_t ipa_pitch_for(size_t row_bytes);
  * 1145-1151).  When enabled, HIP events are recorded on the caller's stream around
  * every stage; ipa_profile_collect() waits for them and returns, per stage, the
  * summed milliseconds and the number of timed intervals since the last collect.
- * Arrays must hold ipa_profile_stage_count() entries. */
+ * Arrays must hold ipa_profile_stage_count() entries.  While timing is enabled the
+ * fused front-end runs its stages strictly one after the other on the caller's
+ * stream (otherwise it overlaps independent stages on helper streams, which makes
+ * per-stage durations meaningless). */
 int ipa_profile_enable(int on);
 int ipa_profile_stage_count(void);
 const char* ipa_profile_stage_name(int stage);
@@ -254,7 +257,10 @@ int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, const int32_t
  *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL;
  *            seg_max as for ipa_hough_accum_u8, may be NULL)
  * The five output planes share one pitch/stride.  Synchronises `stream` only
- * where ipa_canny_u8 does. */
+ * where ipa_canny_u8 does.  Batches of 64 images or more run as two halves that
+ * alternate between `stream` and a helper stream of the library, and the two opens
+ * run on another helper stream beside Canny; all of it is joined back into `stream`
+ * before the call returns, so the caller sees ordinary stream order. */
 size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points);
 int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
                      uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,
