@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--blur", action="store_true", help="variant B: GaussianBlur 5x5 before Canny")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--check", type=int, default=2, help="images per rank verified against the oracle after the run")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="backend of the barrier / max-time reduction (gloo: rehearsal of the N>1 path without N GPUs)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,9 +169,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import imageprocessing_amd as ipa
     from imageprocessing_amd import _native
@@ -224,7 +232,7 @@ def main():
     cnt = (C.c_int * nst)()
     L.ipa_profile_collect(ms, cnt)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
