@@ -35,6 +35,8 @@ SIGNATURES = {
     "ipa_swap_rb_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _vp]),
     "ipa_bitwise_not_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _vp]),
     "ipa_bitwise_or_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _vp]),
+    "ipa_fill_rects_c3_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "ipa_gray_threshold_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _sz, _sz, _i, _i, _i, _d, _d, _i, _vp]),
     "ipa_threshold_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _d, _d, _i, _vp]),
     "ipa_histogram_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _vp, _vp]),
     "ipa_threshold_otsu_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _d, _i, _vp, _vp, _vp]),

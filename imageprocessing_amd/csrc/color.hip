@@ -354,6 +354,72 @@ IPA_EXPORT int ipa_bgr2gray_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_
                            (hipStream_t)stream);
 }
 
+namespace {
+// numpy's slice bounds for a[i:j] on an axis of length n
+__device__ __forceinline__ int slice_bound(int i, int n)
+{
+    if (i < 0) i += n;
+    return i < 0 ? 0 : (i > n ? n : i);
+}
+
+// image[y1:y2, x1:x2] = colour for a list of rectangles (one colour: the order of overlapping
+// rectangles does not matter).  blockIdx.x = rectangle, blockIdx.y = stripe of its rows.
+__global__ __launch_bounds__(256) void k_fill_rects(Plane img, int w, int h, int batch, const int32_t* __restrict__ rects,
+                                                    u32 c0, u32 c1, u32 c2)
+{
+    const int32_t* rc = rects + (size_t)blockIdx.x * 5;
+    const int b = rc[0];
+    if (b < 0 || b >= batch) return;
+    const int x1 = slice_bound(rc[1], w), y1 = slice_bound(rc[2], h), x2 = slice_bound(rc[3], w), y2 = slice_bound(rc[4], h);
+    if (x1 >= x2 || y1 >= y2) return;
+    const int nbytes = (x2 - x1) * 3;
+    const u32 col[3] = {c0, c1, c2};
+    for (int y = y1 + (int)blockIdx.y; y < y2; y += (int)gridDim.y) {
+        u8* row = img.row(b, y) + (size_t)x1 * 3;
+        for (int i = threadIdx.x; i < nbytes; i += 256) row[i] = (u8)col[i % 3];
+    }
+}
+}  // namespace
+
+IPA_EXPORT int ipa_fill_rects_c3_u8(uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, int width, int height, int batch,
+                                    const int32_t* rects, int count, int c0, int c1, int c2, void* stream)
+{
+    CHECK_DIMS();
+    IPA_REQUIRE(count >= 0, IPA_ERR_ARG, "fill_rects: negative count");
+    if (count == 0) return IPA_OK;
+    IPA_REQUIRE(rects != nullptr, IPA_ERR_ARG, "fill_rects: rects is NULL");
+    IPA_REQUIRE((unsigned)c0 < 256u && (unsigned)c1 < 256u && (unsigned)c2 < 256u, IPA_ERR_ARG, "fill_rects: colour out of range");
+    Plane s = mkplane(bgr, bgr_pitch, bgr_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width * 3, batch), IPA_ERR_ALIGN,
+                "fill_rects: pointer/pitch must be 16-byte aligned and pitch >= row bytes");
+    for (int r0 = 0; r0 < count; r0 += 65535 * 32) {
+        const int n = count - r0 < 65535 * 32 ? count - r0 : 65535 * 32;
+        hipLaunchKernelGGL(k_fill_rects, dim3((unsigned)n, 16), dim3(256), 0, (hipStream_t)stream, s, width, height, batch,
+                           rects + (size_t)r0 * 5, (u32)c0, (u32)c1, (u32)c2);
+        IPA_LAUNCH_CHECK();
+    }
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_gray_threshold_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
+                                     uint8_t* thresh, size_t plane_pitch, size_t plane_stride, int width, int height,
+                                     int batch, double thresh_val, double maxval, int type, void* stream)
+{
+    CHECK_DIMS();
+    IPA_REQUIRE(type == IPA_THRESH_BINARY || type == IPA_THRESH_BINARY_INV, IPA_ERR_ARG, "gray_threshold: unknown threshold type");
+    Plane s = mkplane(bgr, bgr_pitch, bgr_stride), g = mkplane(gray, plane_pitch, plane_stride),
+          t = mkplane(thresh, plane_pitch, plane_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width * 3, batch) && plane_ok(g, (size_t)width, batch) && plane_ok(t, (size_t)width, batch),
+                IPA_ERR_ALIGN, "gray_threshold: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    // cv::threshold on 8-bit data: floor(thresh), maxval rounded and saturated
+    double ft = floor(thresh_val);
+    const int it = ft < -1 ? -1 : (ft > 256 ? 256 : (int)ft);
+    long mv = lrint(maxval);
+    const int imax = mv < 0 ? 0 : (mv > 255 ? 255 : (int)mv);
+    return launch_bgr2gray(s, g, t, nullptr, 0, 0, width, height, batch, it, imax, type == IPA_THRESH_BINARY_INV,
+                           (hipStream_t)stream);
+}
+
 IPA_EXPORT int ipa_gray2bgr_u8(const uint8_t* gray, size_t gray_pitch, size_t gray_stride, uint8_t* bgr,
                                size_t bgr_pitch, size_t bgr_stride, int width, int height, int batch, void* stream)
 {

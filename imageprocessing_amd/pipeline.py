@@ -147,3 +147,49 @@ def edges_and_lines(img, lo=50, hi=150, hough_threshold=100, blur=False):
     gray -> [GaussianBlur 5x5] -> Canny(lo, hi) -> HoughLines(edges, 1, pi/180, hough_threshold)."""
     r = front_end(img, canny=(lo, hi), blur=blur, hough_threshold=hough_threshold)
     return r.gray, r.edges, r.lines
+
+
+def erase_rects(bgr: DevImage, rects, bg_color=(255, 255, 255)) -> None:
+    """``image_rect[y1:y2, x1:x2] = bg_color`` of draw_rectangles (umlClassdiagram.py:107-116) for a
+    device-resident batch, in place.  ``rects``: rows of (image index, x1, y1, x2, y2) with numpy
+    slice semantics; a (n, 4) array addresses image 0."""
+    L = _native.lib()
+    r = np.asarray(rects, dtype=np.int64)
+    if r.size == 0:
+        return
+    if r.ndim == 1:
+        r = r[None, :]
+    if r.shape[1] == 4:
+        r = np.concatenate([np.zeros((r.shape[0], 1), np.int64), r], axis=1)
+    if r.shape[1] != 5:
+        raise error("erase_rects: rects must have 4 or 5 columns")
+    if bgr.channels != 3:
+        raise error("erase_rects: a 3-channel image is required")
+    if np.abs(r).max() > 2 ** 31 - 1:
+        raise error("erase_rects: coordinate out of range")
+    dev = torch.from_numpy(np.ascontiguousarray(r.astype(np.int32))).to(bgr.t.device)
+    c = [int(v) for v in bg_color]
+    if len(c) != 3 or any(v < 0 or v > 255 for v in c):
+        raise error("erase_rects: bg_color must be three values in 0..255")
+    check(L.ipa_fill_rects_c3_u8(bgr.ptr, bgr.pitch, bgr.stride, bgr.width, bgr.height, bgr.batch, dev.data_ptr(),
+                                 int(r.shape[0]), c[0], c[1], c[2], stream_ptr()))
+
+
+def rebinarize(img, rects, thresh_val=128, bg_color=(255, 255, 255), maxval=255, thresh_type=cv2api.THRESH_BINARY_INV):
+    """The second binarisation of the parsers (umlClassdiagram.py:1117-1121): erase the rectangle
+    line areas from the BGR image, then gray + threshold, without leaving the device.
+
+    ``img``: numpy uint8[H,W,3] / [N,H,W,3] or ROCm tensor (a tensor is modified in place, like the
+    reference's ``image_rect``; numpy input is copied).  Returns (erased BGR, gray, thresh) of the
+    same kind as ``img``."""
+    L = _native.lib()
+    batched = getattr(img, "ndim", 3) == 4
+    s = upload(img, 3, batched=batched)
+    erase_rects(s, rects, bg_color)
+    planes = DevImage.empty(2 * s.batch, s.height, s.width, 1)
+    g = DevImage(planes.t[: s.batch], s.batch, s.height, s.width, 1)
+    t = DevImage(planes.t[s.batch :], s.batch, s.height, s.width, 1)
+    check(L.ipa_gray_threshold_u8(s.ptr, s.pitch, s.stride, g.ptr, t.ptr, g.pitch, g.stride, s.width, s.height, s.batch,
+                                  float(thresh_val), float(maxval), int(thresh_type), stream_ptr()))
+    to = (lambda d: d.to_tensor(not batched)) if isinstance(img, torch.Tensor) else (lambda d: d.to_numpy(not batched))
+    return to(s), to(g), to(t)

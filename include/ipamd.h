@@ -107,6 +107,26 @@ int ipa_bitwise_or_u8(const uint8_t* a, size_t a_pitch, size_t a_stride,
                       uint8_t* dst, size_t dst_pitch, size_t dst_stride,
                       int row_bytes, int height, int batch, void* stream);
 
+/* image_rect[y1:y2, x1:x2] = bg_color, the erase step of draw_rectangles
+ * (umlClassdiagram.py:107-116, 1117; umlSequencediagram.py:108-141): fills `count`
+ * rectangles of one colour in a batch of BGR images IN PLACE, so that the images stay
+ * resident for the second binarisation.  `rects` = int32[count][5] in DEVICE memory:
+ * image index, x1, y1, x2, y2 with numpy slice semantics (negative bounds count from
+ * the end, bounds are clipped, empty ranges do nothing; rectangles of images outside
+ * the batch are ignored). */
+int ipa_fill_rects_c3_u8(uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
+                         int width, int height, int batch,
+                         const int32_t* rects, int count, int c0, int c1, int c2, void* stream);
+
+/* threshold_image(cv2.cvtColor(img, COLOR_BGR2GRAY)) in one pass over the BGR input: the
+ * re-binarisation after the erase (umlClassdiagram.py:1120-1121; umlSequencediagram.py:605)
+ * and the first step of every parser (umlClassdiagram.py:14-20).  gray and thresh share
+ * one pitch / stride; `type` is IPA_THRESH_BINARY or IPA_THRESH_BINARY_INV. */
+int ipa_gray_threshold_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
+                          uint8_t* gray, uint8_t* thresh, size_t plane_pitch, size_t plane_stride,
+                          int width, int height, int batch,
+                          double thresh_val, double maxval, int type, void* stream);
+
 /* ---- thresholds -------------------------------------------------------- */
 
 /* cv2.threshold(gray, thresh, maxval, THRESH_BINARY | THRESH_BINARY_INV):

@@ -450,3 +450,51 @@ def test_front_end_point_list_overflow_retries():
     e = fr.canny(fr.bgr2gray(bgr), 50, 150)
     assert np.count_nonzero(e) > 16
     assert np.array_equal(fe.accum[0].cpu().numpy(), fr.hough_accum(e, 1, np.pi / 180))
+
+
+# ------------------------------------------------------------------ erase + second binarisation
+def _erase_np(img, rects, color):
+    out = img.copy()
+    for r in rects:
+        b, x1, y1, x2, y2 = (0, *r) if len(r) == 4 else r
+        if out.ndim == 4:
+            if 0 <= b < out.shape[0]:
+                out[b, y1:y2, x1:x2] = color
+        elif b == 0:
+            out[y1:y2, x1:x2] = color
+    return out
+
+
+def test_rebinarize_single_image_numpy_slices(cd_bgr):
+    # the erase of draw_rectangles (umlClassdiagram.py:107-116) follows numpy's slice rules:
+    # negative bounds, bounds past the edge, empty and inverted ranges
+    h, w = cd_bgr.shape[:2]
+    rects = [(10, 20, 200, 24), (5, 5, 8, 300), (-50, -40, w + 30, -10), (100, 100, 100, 200), (300, 50, 200, 80),
+             (0, 0, 1, 1), (w - 1, h - 1, w, h), (-10 * w, 30, 12, 33), (40, -10 * h, 44, 7)]
+    for color, t in (((255, 255, 255), 150), ((0, 17, 250), 100)):
+        img, gray, thr = cv2.rebinarize(cd_bgr, rects, thresh_val=t, bg_color=color)
+        ref = _erase_np(cd_bgr, rects, color)
+        assert np.array_equal(img, ref)
+        g = fr.bgr2gray(ref)
+        assert np.array_equal(gray, g)
+        assert np.array_equal(thr, fr.threshold(g, t, 255, 1)[1])
+    assert np.array_equal(cv2.rebinarize(cd_bgr, [], 128)[0], cd_bgr)
+
+
+def test_rebinarize_batch_and_tensor_in_place():
+    rng = np.random.default_rng(3)
+    imgs = rng.integers(0, 256, (3, 61, 83, 3), dtype=np.uint8)
+    rects = [(0, 1, 2, 30, 9), (2, 40, 0, 83, 61), (1, -20, -20, 100, 100), (7, 0, 0, 5, 5), (-1, 0, 0, 5, 5)]
+    img, gray, thr = cv2.rebinarize(imgs, rects, thresh_val=127.5, bg_color=(9, 8, 7), thresh_type=cv2.THRESH_BINARY)
+    ref = _erase_np(imgs, rects, (9, 8, 7))
+    assert np.array_equal(img, ref)
+    for i in range(3):
+        g = fr.bgr2gray(ref[i])
+        assert np.array_equal(gray[i], g)
+        assert np.array_equal(thr[i], fr.threshold(g, 127.5, 255, 0)[1])
+    import torch
+
+    t = torch.from_numpy(imgs[0]).cuda()
+    out, g2, _ = cv2.rebinarize(t, [(3, 4, 20, 30)], 128)
+    assert isinstance(out, torch.Tensor) and np.array_equal(out.cpu().numpy(), _erase_np(imgs[0], [(3, 4, 20, 30)], (255, 255, 255)))
+    assert np.array_equal(g2.cpu().numpy(), fr.bgr2gray(out.cpu().numpy()))
