@@ -85,7 +85,7 @@ class FrontEnd:
             bgr.ptr, bgr.pitch, bgr.stride, p[0].ptr, p[1].ptr, p[2].ptr, p[3].ptr, p[4].ptr, p[0].pitch, p[0].stride,
             self.accum.data_ptr() if self.hough else None, self.accum.stride(0) if self.hough else 0,
             self.seg_max.data_ptr() if self.hough else None,
-            self.max_points, self.point_counts.data_ptr() if self.hough else None,
+            self.max_points if self.hough else 1, self.point_counts.data_ptr() if self.hough else None,
             self.width, self.height, self.batch, self.thresh_val, self.vert_len, self.horiz_len, self.iterations,
             float(self.canny[0]), float(self.canny[1]), 1 if self.blur else 0,
             self.ws.data_ptr(), self.ws.numel(), stream_ptr()))
@@ -193,3 +193,39 @@ def rebinarize(img, rects, thresh_val=128, bg_color=(255, 255, 255), maxval=255,
                                   float(thresh_val), float(maxval), int(thresh_type), stream_ptr()))
     to = (lambda d: d.to_tensor(not batched)) if isinstance(img, torch.Tensor) else (lambda d: d.to_numpy(not batched))
     return to(s), to(g), to(t)
+
+
+def segments_batch(masks, max_boxes=4096):
+    """get_segments of the parsers for a batch of masks uint8[N,H,W] (numpy or ROCm tensor):
+    per image the list of (x, y, w, h) of cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
+    + cv2.boundingRect, in cv2's order (umlClassdiagram.py:33-36)."""
+    L = _native.lib()
+    s = upload(masks, 1, batched=True)
+    n = s.batch
+    if n == 0:
+        return []
+    dev = s.t.device
+    max_segments = 0
+    while True:
+        boxes = torch.empty((n, max(max_boxes, 1), 4), dtype=torch.int32, device=dev)
+        counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        ws = workspace(L.ipa_segments_workspace_bytes(s.width, s.height, n, max_segments))
+        check(L.ipa_segments_u8(s.ptr, s.pitch, s.stride, s.width, s.height, n, max_segments, boxes.data_ptr(), max_boxes,
+                                counts.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()))
+        c = counts.cpu().numpy()
+        if (c < 0).any():  # more runs than planned for: allow every pixel to be its own run
+            max_segments = s.width * s.height
+            continue
+        if c.max(initial=0) > max_boxes:
+            max_boxes = int(c.max())
+            continue
+        b = boxes.cpu().numpy()
+        return [[tuple(int(v) for v in b[i, k]) for k in range(int(c[i]))] for i in range(n)]
+
+
+def get_segments(lines, max_boxes=4096):
+    """get_segments(lines) of the parsers (umlClassdiagram.py:33-36) for one mask: list of (x, y, w, h)."""
+    m = lines if isinstance(lines, torch.Tensor) else np.asarray(lines)
+    if m.ndim != 2:
+        raise error("get_segments: a single-channel 2-D mask is required")
+    return segments_batch(m[None], max_boxes)[0]

@@ -259,6 +259,24 @@ int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, const int32_t
                         int numangle, int numrho, int batch,
                         int threshold, uint64_t* keys, int capacity, int32_t* peak_counts, void* stream);
 
+/* ---- segments: external contours -> bounding rectangles --------------------- */
+
+/* get_segments(lines) of the parsers (umlClassdiagram.py:33-36, umlSequencediagram.py:36-39,
+ * umlActivitydiagram.py:47-50, umlStateDiagram.py:33-36):
+ *     contours, _ = cv2.findContours(lines, cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+ *     segments = [cv2.boundingRect(c) for c in contours]
+ * For image b, boxes + b*max_boxes*4 receives up to max_boxes rectangles (x, y, w, h) of the
+ * 8-connected components of the non-zero pixels that are not enclosed by another component,
+ * in cv2's order (by first pixel in raster order, last first); counts[b] receives their number
+ * (may exceed max_boxes: then the caller retries with more room), or -1 when the image has
+ * more row segments (runs of equal pixels within a row) than `max_segments` (0 = a default of
+ * about width*height/64): retry with a larger bound, at most width*height. */
+size_t ipa_segments_workspace_bytes(int width, int height, int batch, int max_segments);
+int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t mask_stride,
+                    int width, int height, int batch, int max_segments,
+                    int32_t* boxes, int max_boxes, int32_t* counts,
+                    void* ws, size_t ws_bytes, void* stream);
+
 /* ---- fused front-end ---------------------------------------------------- */
 
 /* One pass of the whole raster front-end over a batch of BGR images: the

@@ -683,6 +683,108 @@ FR_API int fr_hough_peaks(const int* accum, int numangle, int numrho, double rho
     return (int)cnt;
 }
 
+/* ---- external contours -> bounding rectangles ------------------------------------------
+ * get_segments of the parsers (umlClassdiagram.py:33-36, umlSequencediagram.py:36-39,
+ * umlActivitydiagram.py:47-50, umlStateDiagram.py:33-36):
+ *     contours, _ = cv2.findContours(lines, cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+ *     segments = [cv2.boundingRect(c) for c in contours]
+ * Restated from the published algorithm (Suzuki & Abe 1985, "Topological structural analysis
+ * of digitized binary images by border following") as OpenCV's findContours applies it: the
+ * image is binarised (non-zero -> 1) inside a one-pixel zero frame and scanned in raster order;
+ * a pixel 1 whose left neighbour is 0 starts an outer border; in RETR_EXTERNAL mode the border
+ * is followed only if the last border pixel met on the row (LNBD) does not carry a positive
+ * mark, i.e. the start does not lie inside an already followed border; followed pixels are
+ * marked +2, or -126 where the border has background on its right.  Contours come out in
+ * reverse order of discovery (each new contour is linked in front of its siblings).  The
+ * bounding rectangle of the followed border is the bounding rectangle of the component.
+ * Returns the number of rectangles found; at most `cap` are written as (x, y, w, h). */
+FR_API int fr_external_boxes(const u8* src, size_t sp, int w, int h, int* boxes, int cap)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int step = w + 2;
+    signed char* img = (signed char*)calloc((size_t)step * (h + 2), 1);
+    int* found = NULL;
+    int nfound = 0, room = 0;
+    if (!img) return -1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) img[(size_t)(y + 1) * step + x + 1] = src[(size_t)y * sp + x] ? 1 : 0;
+    /* E, NE, N, NW, W, SW, S, SE: counter-clockwise on the screen, twice */
+    int deltas[16];
+    const int d8[8] = {1, -step + 1, -step, -step - 1, -1, step - 1, step, step + 1};
+    for (int i = 0; i < 16; i++) deltas[i] = d8[i & 7];
+    for (int y = 1; y <= h; y++) {
+        signed char* row = img + (size_t)y * step;
+        int prev = 0, lnbd = 0; /* LNBD restarts at the frame column of every row */
+        for (int x = 1; x <= w; x++) {
+            int p = row[x];
+            if (p == prev) continue;
+            if (prev == 0 && p == 1 && row[lnbd] <= 0) {
+                /* follow the outer border that starts here */
+                signed char* i0 = row + x;
+                signed char *i1, *i3, *i4 = NULL;
+                int s = 4, s_end = 4;
+                int x0 = x, x1 = x, y0 = y, y1 = y;
+                do {
+                    s = (s - 1) & 7;
+                    i1 = i0 + deltas[s];
+                } while (*i1 == 0 && s != s_end);
+                if (s == s_end) {
+                    *i0 = (signed char)(2 | -128); /* isolated pixel */
+                } else {
+                    i3 = i0;
+                    for (;;) {
+                        s_end = s;
+                        while (s < 15) {
+                            i4 = i3 + deltas[++s];
+                            if (*i4 != 0) break;
+                        }
+                        s &= 7;
+                        if ((unsigned)(s - 1) < (unsigned)s_end)
+                            *i3 = (signed char)(2 | -128); /* background on the right of the border */
+                        else if (*i3 == 1)
+                            *i3 = 2;
+                        {
+                            const long off = (long)(i3 - img);
+                            const int py = (int)(off / step), px = (int)(off % step);
+                            if (px < x0) x0 = px;
+                            if (px > x1) x1 = px;
+                            if (py < y0) y0 = py;
+                            if (py > y1) y1 = py;
+                        }
+                        if (i4 == i0 && i3 == i1) break;
+                        i3 = i4;
+                        s = (s + 4) & 7;
+                    }
+                }
+                if (nfound == room) {
+                    room = room ? room * 2 : 256;
+                    int* nf = (int*)realloc(found, sizeof(int) * 4 * (size_t)room);
+                    if (!nf) {
+                        free(found);
+                        free(img);
+                        return -1;
+                    }
+                    found = nf;
+                }
+                found[4 * nfound + 0] = x0 - 1;
+                found[4 * nfound + 1] = y0 - 1;
+                found[4 * nfound + 2] = x1 - x0 + 1;
+                found[4 * nfound + 3] = y1 - y0 + 1;
+                nfound++;
+                p = row[x];
+            }
+            prev = p;
+            if (prev & -2) lnbd = x; /* a marked border pixel */
+        }
+    }
+    for (int i = 0; i < nfound && i < cap; i++)
+        for (int k = 0; k < 4; k++) boxes[4 * i + k] = found[4 * (nfound - 1 - i) + k];
+    free(found);
+    free(img);
+    return nfound;
+}
+
+
 /* ------------------------------------------------------------------ */
 /* The caller compositions of the reference, restated for the CPU baseline:
  * load_image_from_file / threshold_image / extract_lines

@@ -202,6 +202,19 @@ def hough_lines(img, rho, theta, threshold):
     return hough_peaks(hough_accum(img, rho, theta), rho, theta, threshold)
 
 
+def external_boxes(mask, cap=1 << 20):
+    """Bounding rectangles (x, y, w, h) of cv2.findContours(mask, RETR_EXTERNAL, ...) in cv2's order."""
+    m = _c(np.asarray(mask, dtype=np.uint8))
+    h, w = m.shape
+    out = np.zeros((max(cap, 1), 4), np.int32)
+    f = lib().fr_external_boxes
+    f.restype = C.c_int
+    n = f(_p(m), C.c_size_t(m.strides[0] if h else 0), C.c_int(w), C.c_int(h), out.ctypes.data_as(C.c_void_p), C.c_int(cap))
+    if n < 0:
+        raise MemoryError("fr_external_boxes")
+    return out[: min(n, cap)].copy()
+
+
 def front_end(bgr, t=128, line_len=15, iterations=2, c_lo=50.0, c_hi=150.0, with_hough=True):
     """gray, thresh, vlines, hlines, edges, accum for one BGR image (CPU baseline unit of work)."""
     bgr = _c(bgr)

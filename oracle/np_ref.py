@@ -290,3 +290,39 @@ def adaptive_threshold_gaussian_ref(gray, maxv, typ, block, C):
         out = out + (tp[r + i : r + i + h] + tp[r - i : r - i + h]) * k[r + i]
     mean = np.clip(np.rint(out), 0, 255).astype(np.int32)
     return _adaptive_compare(gray, mean, maxv, typ, C)
+
+
+def external_boxes(mask: np.ndarray) -> np.ndarray:
+    """Topological statement of findContours(RETR_EXTERNAL) + boundingRect: the 8-connected
+    components of the non-zero pixels that are not enclosed by another component (they touch
+    the image border or the 4-connected background region that reaches the border), as
+    (x, y, w, h), ordered by their first pixel in raster order, last first (cv2's order)."""
+    from scipy import ndimage
+
+    m = np.asarray(mask) != 0
+    h, w = m.shape
+    if h == 0 or w == 0:
+        return np.zeros((0, 4), np.int32)
+    fg, nf = ndimage.label(m, structure=np.ones((3, 3), int))
+    # background with a one-pixel frame, 4-connected; the frame's region is the outside
+    bgm = np.pad(~m, 1, constant_values=True)
+    bg, _ = ndimage.label(bgm, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    outer = bg == bg[0, 0]
+    # pixels of the image that have an outside pixel among their 4 neighbours
+    near = np.zeros_like(m)
+    o = outer
+    near |= o[1:-1, :-2] | o[1:-1, 2:] | o[:-2, 1:-1] | o[2:, 1:-1]
+    ext = np.unique(fg[m & near])
+    boxes = []
+    objs = ndimage.find_objects(fg)
+    first = {}
+    ys, xs = np.nonzero(m)
+    lab = fg[ys, xs]
+    _, idx = np.unique(lab, return_index=True)  # raster order: first occurrence
+    for k, i in zip(lab[idx], idx):
+        first[int(k)] = int(ys[i]) * w + int(xs[i])
+    for k in ext:
+        sl = objs[int(k) - 1]
+        boxes.append((first[int(k)], sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start))
+    boxes.sort(key=lambda t: -t[0])
+    return np.array([b[1:] for b in boxes], np.int32).reshape(-1, 4)

@@ -398,7 +398,8 @@ def _check_front_end(res, bgr, t, vl, hl, it, lo, hi, blur):
     src = fr.gaussian_blur(g, (5, 5), 0) if blur else g
     e = fr.canny(src, lo, hi)
     assert np.array_equal(res.edges, e)
-    assert np.array_equal(res.accum.cpu().numpy(), fr.hough_accum(e, 1, np.pi / 180))
+    if res.accum is not None:
+        assert np.array_equal(res.accum.cpu().numpy(), fr.hough_accum(e, 1, np.pi / 180))
 
 
 @pytest.mark.parametrize("t", [150, 128, 100])
@@ -498,3 +499,109 @@ def test_rebinarize_batch_and_tensor_in_place():
     out, g2, _ = cv2.rebinarize(t, [(3, 4, 20, 30)], 128)
     assert isinstance(out, torch.Tensor) and np.array_equal(out.cpu().numpy(), _erase_np(imgs[0], [(3, 4, 20, 30)], (255, 255, 255)))
     assert np.array_equal(g2.cpu().numpy(), fr.bgr2gray(out.cpu().numpy()))
+
+
+# ------------------------------------------------------------------ external contours -> rectangles
+# Expected values: the oracle's border-following restatement of findContours(RETR_EXTERNAL) +
+# boundingRect ("restatement": no cv2-written contour artefact exists, parity unpinned).
+def _seg_rings(h, w):
+    m = np.zeros((h, w), np.uint8)
+    cy, cx = h // 2, w // 2
+    for r in range(3, min(cy, cx) - 1, 4):
+        m[cy - r, cx - r : cx + r + 1] = 255
+        m[cy + r, cx - r : cx + r + 1] = 255
+        m[cy - r : cy + r + 1, cx - r] = 255
+        m[cy - r : cy + r + 1, cx + r] = 255
+    m[cy, cx] = 255
+    m[0, 0] = 255
+    m[h - 1, w - 2 : w] = 255
+    return m
+
+
+def _seg_same(got, mask):
+    want = fr.external_boxes(mask)
+    assert len(got) == len(want), (len(got), len(want))
+    assert np.array_equal(np.asarray(got, dtype=np.int64).reshape(-1, 4), want)
+
+
+def test_segments_known_answers():
+    m = np.zeros((20, 30), np.uint8)
+    m[2, 3:25] = 255
+    m[10:18, 7] = 255
+    assert cv2.get_segments(m) == [(7, 10, 1, 8), (3, 2, 22, 1)]
+    m = np.zeros((9, 9), np.uint8)
+    m[1, 1:7] = m[7, 1:8] = 255
+    m[1:8, 1] = 255
+    m[2:8, 7] = 255
+    m[4, 4] = 255
+    assert cv2.get_segments(m) == [(1, 1, 7, 7)]  # diagonal corner still encloses
+    m[2, 7] = 0
+    assert cv2.get_segments(m) == [(4, 4, 1, 1), (1, 1, 7, 7)]
+    assert cv2.get_segments(np.zeros((5, 7), np.uint8)) == []
+    assert cv2.get_segments(np.full((5, 7), 9, np.uint8)) == [(0, 0, 7, 5)]
+    assert cv2.get_segments(np.ones((1, 1), np.uint8)) == [(0, 0, 1, 1)]
+    assert cv2.get_segments(np.zeros((1, 1), np.uint8)) == []
+
+
+@pytest.mark.parametrize("h,w", [(1, 40), (33, 1), (17, 31), (48, 65), (70, 129), (64, 64), (131, 2049), (300, 97)])
+def test_segments_random_masks(h, w):
+    rng = np.random.default_rng(h * 131 + w)
+    for p in (0.02, 0.3, 0.5, 0.62, 0.85):
+        m = ((rng.random((h, w)) < p) * rng.integers(1, 256, (h, w))).astype(np.uint8)
+        _seg_same(cv2.get_segments(m), m)
+
+
+def test_segments_nested_rings_and_blobs():
+    for h, w in ((41, 57), (64, 64), (9, 70), (257, 300)):
+        m = _seg_rings(h, w)
+        _seg_same(cv2.get_segments(m), m)
+    from scipy import ndimage
+
+    rng = np.random.default_rng(5)
+    sm = ndimage.gaussian_filter(rng.random((400, 520)).astype(np.float32), 3.0)
+    for q in (0.3, 0.5, 0.7):
+        m = (sm > np.quantile(sm, q)).astype(np.uint8) * 255
+        _seg_same(cv2.get_segments(m), m)
+
+
+def test_segments_line_masks_of_the_parsers(cd_bgr, login_bgr):
+    # extract_lines -> get_segments (umlClassdiagram.py:22-36) end to end on the device
+    for bgr, t in ((cd_bgr, 150), (login_bgr, 128), (uml_like(7, 600, 800), 128)):
+        res = cv2.front_end(bgr, thresh_val=t, vert_len=15, horiz_len=15, iterations=2, hough=False)
+        assert res.accum is None and res.lines is None
+        _check_front_end(res, bgr, t, 15, 15, 2, 50, 150, False)
+        for mask in (res.vlines, res.hlines, res.thresh):
+            _seg_same(cv2.get_segments(mask), mask)
+
+
+def test_segments_batch_tensor_and_overflow_retries():
+    rng = np.random.default_rng(9)
+    masks = ((rng.random((5, 96, 160)) < 0.5) * 255).astype(np.uint8)  # dense: more runs than planned for
+    masks[3] = 0
+    masks[4] = 255
+    got = cv2.segments_batch(masks, max_boxes=8)  # and more rectangles than asked for
+    assert len(got) == 5
+    for i in range(5):
+        _seg_same(got[i], masks[i])
+    t = torch.from_numpy(masks[:2]).cuda()
+    got = cv2.segments_batch(t)
+    for i in range(2):
+        _seg_same(got[i], masks[i])
+
+
+def test_segments_large_image_property():
+    # 4K: every rectangle of a sparse mask of separated bars comes back once, bottom-most first
+    h, w = 2160, 3840
+    m = np.zeros((h, w), np.uint8)
+    rng = np.random.default_rng(2)
+    want = []
+    for gy in range(20, h - 40, 48):
+        for gx in range(20, w - 200, 256):
+            bw, bh = int(rng.integers(1, 180)), int(rng.integers(1, 30))
+            m[gy : gy + bh, gx : gx + bw] = 255
+            want.append((gx, gy, bw, bh))
+    got = cv2.get_segments(m, max_boxes=len(want))
+    assert sorted(got) == sorted(want)
+    keys = [(y, x) for x, y, _, _ in got]
+    assert keys == sorted(keys, reverse=True)
+    _seg_same(got, m)

@@ -190,3 +190,68 @@ def test_otsu_c_vs_numpy(cd_bgr):
         assert fr.threshold(img, 0, 255, 8)[0] == nr.otsu(img)
         t, d = fr.threshold(img, 0, 255, 9)
         assert np.array_equal(d, nr.threshold(img, 0, 255, 9)[1])
+
+
+# ------------------------------------------------------------------ external contours -> rectangles
+def _rings(h, w):
+    """Nested square rings around (h/2, w/2) plus satellites inside and outside of them."""
+    m = np.zeros((h, w), np.uint8)
+    cy, cx = h // 2, w // 2
+    for r in range(3, min(cy, cx) - 1, 4):
+        m[cy - r : cy + r + 1, cx - r : cx + r + 1] = 0
+        m[cy - r, cx - r : cx + r + 1] = 255
+        m[cy + r, cx - r : cx + r + 1] = 255
+        m[cy - r : cy + r + 1, cx - r] = 255
+        m[cy - r : cy + r + 1, cx + r] = 255
+    m[cy, cx] = 255
+    m[0, 0] = 255
+    m[h - 1, w - 2 : w] = 255
+    return m
+
+
+def test_external_boxes_known_answers():
+    # get_segments (umlClassdiagram.py:33-36): two bars, listed bottom-most first like cv2 does
+    m = np.zeros((20, 30), np.uint8)
+    m[2, 3:25] = 255
+    m[10:18, 7] = 255
+    assert fr.external_boxes(m).tolist() == [[7, 10, 1, 8], [3, 2, 22, 1]]
+    # a ring hides what is inside it; a diagonal chain is one component
+    m = np.zeros((12, 12), np.uint8)
+    m[1:10, 1:10] = 255
+    m[2:9, 2:9] = 0
+    m[5, 5] = 255
+    for i in range(3):
+        m[9 + i, 9 + i] = 255
+    assert fr.external_boxes(m).tolist() == [[1, 1, 11, 11]]
+    # a ring open through a diagonal gap still encloses (background is 4-connected)
+    m = np.zeros((9, 9), np.uint8)
+    m[1, 1:7] = m[7, 1:8] = 255
+    m[1:8, 1] = 255
+    m[2:8, 7] = 255  # (1,7) missing: corner gap closed diagonally by (1,6)-(2,7)
+    m[4, 4] = 255
+    assert fr.external_boxes(m).tolist() == [[1, 1, 7, 7]]
+    m[2, 7] = 0  # now a real gap
+    assert fr.external_boxes(m).tolist() == [[4, 4, 1, 1], [1, 1, 7, 7]]
+    assert fr.external_boxes(np.zeros((5, 7), np.uint8)).shape == (0, 4)
+    assert fr.external_boxes(np.full((5, 7), 9, np.uint8)).tolist() == [[0, 0, 7, 5]]
+    assert fr.external_boxes(np.ones((1, 1), np.uint8)).tolist() == [[0, 0, 1, 1]]
+
+
+def test_external_boxes_c_vs_numpy():
+    rng = np.random.default_rng(11)
+    masks = [_rings(41, 57), _rings(64, 64), _rings(9, 70)]
+    for p in (0.05, 0.3, 0.5, 0.62, 0.8):
+        for h, w in ((1, 40), (33, 1), (17, 31), (48, 65), (70, 129)):
+            masks.append(((rng.random((h, w)) < p) * rng.integers(1, 256, (h, w))).astype(np.uint8))
+    for m in masks:
+        a, b = fr.external_boxes(m), nr.external_boxes(m)
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_external_boxes_on_line_masks(cd_bgr):
+    t = fr.threshold(fr.bgr2gray(cd_bgr), 150, 255, 1)[1]
+    for ks in ((1, 15), (15, 1)):
+        lines = fr.morphology_ex(t, 2, ks, 2)
+        a = fr.external_boxes(lines)
+        assert len(a) >= 2 and np.array_equal(a, nr.external_boxes(lines))
+    assert np.array_equal(fr.external_boxes(t), nr.external_boxes(t))
