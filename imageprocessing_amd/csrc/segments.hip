@@ -69,36 +69,50 @@ __global__ __launch_bounds__(256) void k_seg_count(const u32* __restrict__ bits,
     if (lane == 0) A.rowcnt[(size_t)b * h + y] = n + 1;
 }
 
+// Inclusive scan of one value per thread over a 1024-thread workgroup (16 waves): shuffles inside
+// the wave, the 16 wave totals through LDS.  Two barriers; s_wave must hold 16 words.
+__device__ __forceinline__ u32 block_scan_1024(u32 v, u32* s_wave, u32& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 scan = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)scan, o);
+        if (lane >= o) scan += t;
+    }
+    __syncthreads();  // s_wave may still be read by the previous round
+    if (lane == 63) s_wave[wv] = scan;
+    __syncthreads();
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 t = s_wave[k];
+        before += k < wv ? t : 0u;
+        all += t;
+    }
+    total = all;
+    return scan + before;
+}
+
 // one workgroup per image: exclusive scan of the row counts
 __global__ __launch_bounds__(1024) void k_seg_scan(int h, SegArrays A)
 {
-    __shared__ u32 s_part[1024];
-    __shared__ u32 s_base;
+    __shared__ u32 s_wave[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const u32* cnt = A.rowcnt + (size_t)b * h;
     u32* off = A.rowoff + (size_t)b * (h + 1);
-    if (tid == 0) s_base = 0;
-    __syncthreads();
+    u32 base = 0;
     for (int y0 = 0; y0 < h; y0 += 1024) {
         const int y = y0 + tid;
         const u32 c = y < h ? cnt[y] : 0u;
-        s_part[tid] = c;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-            const u32 v = tid >= o ? s_part[tid - o] : 0u;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
-        }
-        const u32 incl = s_part[tid], base = s_base;
+        u32 total;
+        const u32 incl = block_scan_1024(c, s_wave, total);
         if (y < h) off[y] = base + incl - c;
-        __syncthreads();
-        if (tid == 1023) s_base = base + incl;
-        __syncthreads();
+        base += total;
     }
     if (tid == 0) {
-        off[h] = s_base;
-        A.total[b] = s_base > A.cap ? -1 : (int32_t)s_base;
+        off[h] = base;
+        A.total[b] = base > A.cap ? -1 : (int32_t)base;
     }
 }
 
@@ -159,10 +173,16 @@ __device__ __forceinline__ u32 seg_find(const u32* parent, u32 i)
 
 __device__ __forceinline__ void seg_union(u32* parent, u32 a, u32 c)
 {
+    const u32 a_in = a, c_in = c;
     for (;;) {
         a = seg_find(parent, a);
         c = seg_find(parent, c);
-        if (a == c) return;
+        if (a == c) {
+            // shorten the chains for later finds: a link may always move to a smaller member of its set
+            if (a_in != a) atomicMin(&parent[a_in], a);
+            if (c_in != a) atomicMin(&parent[c_in], a);
+            return;
+        }
         if (a < c) {
             const u32 t = a;
             a = c;
@@ -235,12 +255,15 @@ __global__ __launch_bounds__(256) void k_seg_boxes(const u32* __restrict__ bits,
     const u32 val = seg_value(bits, bpw, bsw, b, (int)y, krow);
     const u32 sx = A.xs[base + i];
     const u32 ex = (i + 1 < A.rowoff[(size_t)b * (h + 1) + y + 1] ? A.xs[base + i + 1] : (u32)w) - 1u;
+    // The extents only ever move outwards and the flag is only ever set, so a (possibly stale)
+    // plain read that already satisfies this segment makes the atomic unnecessary: large sets
+    // would otherwise serialise on their root.
     if (val) {
-        atomicMin(&A.x0[base + r], sx);
-        atomicMax(&A.x1[base + r], ex);
-        atomicMax(&A.y1[base + r], y);
+        if (__builtin_nontemporal_load(&A.x0[base + r]) > sx) atomicMin(&A.x0[base + r], sx);
+        if (__builtin_nontemporal_load(&A.x1[base + r]) < ex) atomicMax(&A.x1[base + r], ex);
+        if (__builtin_nontemporal_load(&A.y1[base + r]) < y) atomicMax(&A.y1[base + r], y);
     } else if (y == 0 || y == (u32)h - 1 || sx == 0 || ex == (u32)w - 1) {
-        atomicOr(&A.flags[base + r], SEG_OUTSIDE);
+        if (!(__builtin_nontemporal_load(&A.flags[base + r]) & SEG_OUTSIDE)) atomicOr(&A.flags[base + r], SEG_OUTSIDE);
     }
 }
 
@@ -273,15 +296,15 @@ __global__ __launch_bounds__(256) void k_seg_extern(const u32* __restrict__ bits
         for (u32 j = seg_locate(xs, fn, nn, sx); j < nn && xs[fn + j] <= ex && !ext; j++)
             if (((vfirst ^ j) & 1u) == 0u) ext = outside(fn + j);
     }
-    if (ext) atomicOr(&A.flags[base + parent[i]], SEG_EXTERNAL);
+    if (ext && !(__builtin_nontemporal_load(&A.flags[base + parent[i]]) & SEG_EXTERNAL))
+        atomicOr(&A.flags[base + parent[i]], SEG_EXTERNAL);
 }
 
 // one workgroup per image: external foreground roots, largest index first
 __global__ __launch_bounds__(1024) void k_seg_emit(const u32* __restrict__ bits, size_t bpw, size_t bsw, int h, SegArrays A,
                                                    int32_t* __restrict__ boxes, int max_boxes, int32_t* __restrict__ counts)
 {
-    __shared__ u32 s_part[1024];
-    __shared__ u32 s_base;
+    __shared__ u32 s_wave[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int32_t tot = A.total[b];
     if (tot < 0) {
@@ -289,8 +312,7 @@ __global__ __launch_bounds__(1024) void k_seg_emit(const u32* __restrict__ bits,
         return;
     }
     const size_t base = (size_t)b * A.cap;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
+    u32 done = 0;
     for (u32 c0 = 0; c0 < (u32)tot; c0 += 1024) {
         const u32 rev = c0 + tid;  // position counted from the end
         bool is = false;
@@ -303,17 +325,10 @@ __global__ __launch_bounds__(1024) void k_seg_emit(const u32* __restrict__ bits,
                 is = seg_value(bits, bpw, bsw, b, (int)y, i - A.rowoff[(size_t)b * (h + 1) + y]) != 0;
             }
         }
-        s_part[tid] = is ? 1u : 0u;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const u32 v = tid >= o ? s_part[tid - o] : 0u;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
-        }
-        const u32 incl = s_part[tid], bs = s_base;
+        u32 total;
+        const u32 incl = block_scan_1024(is ? 1u : 0u, s_wave, total);
         if (is) {
-            const u32 pos = bs + incl - 1;
+            const u32 pos = done + incl - 1;
             if (pos < (u32)max_boxes) {
                 int32_t* o = boxes + ((size_t)b * max_boxes + pos) * 4;
                 const u32 x0 = A.x0[base + i], y0 = A.yy[base + i];
@@ -323,11 +338,9 @@ __global__ __launch_bounds__(1024) void k_seg_emit(const u32* __restrict__ bits,
                 o[3] = (int32_t)(A.y1[base + i] - y0 + 1);
             }
         }
-        __syncthreads();
-        if (tid == 1023) s_base = bs + incl;
-        __syncthreads();
+        done += total;
     }
-    if (tid == 0) counts[b] = (int32_t)s_base;
+    if (tid == 0) counts[b] = (int32_t)done;
 }
 
 u32 seg_capacity(int w, int h, int max_segments)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", default="4k")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="", help="run only the ops whose name contains this text")
     args = ap.parse_args()
     h, w = {"1080p": (1080, 1920), "4k": (2160, 3840)}[args.size]
     import torch
@@ -52,7 +53,7 @@ def main():
     cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
     ws_sizes = [L.ipa_adaptive_threshold_workspace_bytes(w, h, n), L.ipa_gaussian_blur_workspace_bytes(w, h, n),
                 L.ipa_morph_workspace_bytes(w, h, n), L.ipa_canny_workspace_bytes(w, h, n),
-                L.ipa_hough_workspace_bytes(w, h, n, w * h // 4)]
+                L.ipa_hough_workspace_bytes(w, h, n, w * h // 4), L.ipa_segments_workspace_bytes(w, h, n, 0)]
     ws = workspace(max(ws_sizes))
     px = float(n) * h * w
     acc_bytes = 4.0 * (na + 2) * (nr + 2) * n
@@ -63,6 +64,17 @@ def main():
     def morph(op, kw, kh, it, binary, src):
         return lambda: chk(L.ipa_morph_u8(src.ptr, src.pitch, src.stride, out.ptr, out.pitch, out.stride, w, h, n, op, kw, kh,
                                           -1, -1, it, binary, ws.data_ptr(), ws.numel(), st))
+
+    hl = DevImage.empty(n, h, w, 1)
+    chk(L.ipa_morph_u8(thr.ptr, thr.pitch, thr.stride, hl.ptr, hl.pitch, hl.stride, w, h, n, 2, 15, 1, -1, -1, 2, 1,
+                       ws.data_ptr(), ws.numel(), st))
+    boxes = torch.empty((n, 4096, 4), dtype=torch.int32, device="cuda")
+    nbox = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rects = torch.tensor([[i % n, 100 + 7 * i, 50 + 11 * i, 900 + 7 * i, 54 + 11 * i] for i in range(4 * n)], dtype=torch.int32).cuda()
+
+    def segments(src):
+        return lambda: chk(L.ipa_segments_u8(src.ptr, src.pitch, src.stride, w, h, n, 0, boxes.data_ptr(), 4096, nbox.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), st))
 
     ops = [
         ("cvtColor BGR2GRAY", 4 * px, lambda: chk(L.ipa_bgr2gray_u8(bgr.ptr, bgr.pitch, bgr.stride, gray.ptr, gray.pitch, gray.stride, w, h, n, st))),
@@ -82,9 +94,15 @@ def main():
         ("open 15x1 it=2 (gray)", 2 * px, morph(2, 15, 1, 2, 0, gray)),
         ("Canny 50/150", 2 * px, lambda: chk(L.ipa_canny_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 50.0, 150.0, ws.data_ptr(), ws.numel(), st))),
         ("HoughLines accumulator", px + acc_bytes, lambda: chk(L.ipa_hough_accum_u8(edges.ptr, edges.pitch, edges.stride, w, h, n, 1.0, np.pi / 180, acc.data_ptr(), acc.stride(0), seg.data_ptr(), w * h // 4, cnt.data_ptr(), ws.data_ptr(), ws.numel(), st))),
+        ("get_segments (hlines mask)", px, segments(hl)),
+        ("get_segments (thresh mask)", px, segments(thr)),
+        ("erase rects (4 per image)", 0.0, lambda: chk(L.ipa_fill_rects_c3_u8(bgr.ptr, bgr.pitch, bgr.stride, w, h, n, rects.data_ptr(), rects.shape[0], 255, 255, 255, st))),
+        ("cvtColor + threshold fused", 5 * px, lambda: chk(L.ipa_gray_threshold_u8(bgr.ptr, bgr.pitch, bgr.stride, gray.ptr, out.ptr, gray.pitch, gray.stride, w, h, n, 128.0, 255.0, 1, st))),
         ("bitwise_or", 3 * px, lambda: chk(L.ipa_bitwise_or_u8(gray.ptr, gray.pitch, gray.stride, thr.ptr, thr.pitch, thr.stride, out.ptr, out.pitch, out.stride, w, h, n, st))),
     ]
     for name, nbytes, fn in ops:
+        if args.only and args.only not in name:
+            continue
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
