@@ -130,17 +130,15 @@ static size_t chunk_ws_bytes(int width, int height, int batch, int max_points)
     return a.off + 256;
 }
 
-// Large batches run as several chunks that alternate between two streams, each chunk starting
-// when the previous chunk's gray kernel is done: the chunks stay one stage apart, so that an
-// HBM-bound stage of one runs beside an ALU- or LDS-bound stage of the other.  Every chunk has
-// its own part of the workspace.
+// Large batches run as several chunks, each with its own part of the workspace, so that stages
+// bound by different units of the chip can run side by side (see ipa_front_end_u8).
 constexpr int IPA_MAX_CHUNKS = 8;
 static int pipeline_chunks(int batch)
 {
     static int pipe = -1;  // IPA_PIPELINE=<chunks>; 0 or 1: one chain on the caller's stream
     if (pipe < 0) {
         const char* e = getenv("IPA_PIPELINE");
-        pipe = e ? atoi(e) : 2;
+        pipe = e ? atoi(e) : 4;
         if (pipe > IPA_MAX_CHUNKS) pipe = IPA_MAX_CHUNKS;
     }
     // per-stage timing wants the stages one after the other, each over the whole batch
@@ -190,116 +188,181 @@ hipStream_t side_stream(int which)
 }
 }  // namespace
 
-static int front_end_chunk(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray, uint8_t* thresh,
-                           uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch, size_t plane_stride,
-                           int32_t* accum, size_t accum_stride, int32_t* seg_max, int max_points, int32_t* point_counts,
-                           int width, int height, int batch, int thresh_val, int vert_len, int horiz_len, int iterations,
-                           double canny_lo, double canny_hi, int blur5x5, void* ws, size_t ws_bytes, hipStream_t st,
-                           hipEvent_t after_gray = nullptr)
+namespace {
+// One chunk of a front-end call (a run of consecutive images with its own part of the workspace),
+// cut into the three stages the schedules below place on streams:
+//   stage_binarise  gray + threshold + bit plane, then the two opens      (bound by HBM)
+//   stage_edges     [blur] Canny NMS + hysteresis, edge-pixel lists        (vector ALU / latency)
+//   stage_vote      Hough accumulator                                      (LDS atomics)
+struct Chunk {
+    Plane B, G, T, V, H, E;
+    int32_t *accum, *seg_max, *point_counts;
+    size_t accum_stride;
+    int max_points, width, height, batch, tv, KV, AV, KH, AH, blur5x5, lo, hi;
+    FrontWs L;
+    u32* bits;
+    void *canny_ws, *hough_ws, *blur_ws;
+    u8* blur_plane;
+    size_t bpw, bsw;
+};
+
+int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray, uint8_t* thresh,
+               uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch, size_t plane_stride, int32_t* accum,
+               size_t accum_stride, int32_t* seg_max, int max_points, int32_t* point_counts, int width, int height, int batch,
+               int thresh_val, int vert_len, int horiz_len, int iterations, double canny_lo, double canny_hi, int blur5x5,
+               void* ws, size_t ws_bytes)
 {
-    Plane B = mkplane(bgr, bgr_pitch, bgr_stride);
-    Plane G = mkplane(gray, plane_pitch, plane_stride), T = mkplane(thresh, plane_pitch, plane_stride);
-    Plane V = mkplane(vlines, plane_pitch, plane_stride), H = mkplane(hlines, plane_pitch, plane_stride);
-    Plane E = mkplane(edges, plane_pitch, plane_stride);
-    IPA_REQUIRE(plane_ok(B, (size_t)width * 3, batch), IPA_ERR_ALIGN, "front_end: bgr pointer/pitch misaligned");
-    IPA_REQUIRE(plane_ok(G, (size_t)width, batch) && plane_ok(T, (size_t)width, batch) &&
-                    plane_ok(V, (size_t)width, batch) && plane_ok(H, (size_t)width, batch) &&
-                    plane_ok(E, (size_t)width, batch),
+    C.B = mkplane(bgr, bgr_pitch, bgr_stride);
+    C.G = mkplane(gray, plane_pitch, plane_stride), C.T = mkplane(thresh, plane_pitch, plane_stride);
+    C.V = mkplane(vlines, plane_pitch, plane_stride), C.H = mkplane(hlines, plane_pitch, plane_stride);
+    C.E = mkplane(edges, plane_pitch, plane_stride);
+    IPA_REQUIRE(plane_ok(C.B, (size_t)width * 3, batch), IPA_ERR_ALIGN, "front_end: bgr pointer/pitch misaligned");
+    IPA_REQUIRE(plane_ok(C.G, (size_t)width, batch) && plane_ok(C.T, (size_t)width, batch) &&
+                    plane_ok(C.V, (size_t)width, batch) && plane_ok(C.H, (size_t)width, batch) &&
+                    plane_ok(C.E, (size_t)width, batch),
                 IPA_ERR_ALIGN, "front_end: output plane pointer/pitch misaligned");
     IPA_REQUIRE(!accum || point_counts, IPA_ERR_ARG, "front_end: point_counts is NULL");
     IPA_REQUIRE(ws && ws_bytes >= chunk_ws_bytes(width, height, batch, max_points), IPA_ERR_WORKSPACE,
                 "front_end: workspace too small");
-    FrontWs L = front_layout(width, height, batch, max_points);
+    C.accum = accum; C.accum_stride = accum_stride; C.seg_max = seg_max; C.point_counts = point_counts;
+    C.max_points = max_points; C.width = width; C.height = height; C.batch = batch; C.blur5x5 = blur5x5;
+    C.L = front_layout(width, height, batch, max_points);
     Arena ar(ws, ws_bytes);
-    u32* bits = (u32*)ar.take(L.bits_bytes);
-    void* canny_ws = ar.take(L.canny_bytes);
-    void* hough_ws = ar.take(L.hough_bytes);
-    void* blur_ws = ar.take(L.blur_ws_bytes);
-    u8* blur_plane = (u8*)ar.take(L.blur_plane_bytes);
-    const size_t bpw = bits_pitch_words(width), bsw = bpw * (size_t)height;
-    int tv = thresh_val < -1 ? -1 : (thresh_val > 256 ? 256 : thresh_val);
-
-    // gray + THRESH_BINARY_INV plane + its bit plane, one pass over the BGR input
-    int rc;
-    {
-        ProfScope ps(PROF_GRAY_THRESH, st);
-        rc = launch_bgr2gray(B, G, T, bits, bpw, bsw, width, height, batch, tv, 255, 1, st);
-    }
-    if (rc) return rc;
-    if (after_gray) IPA_HIP(hipEventRecord(after_gray, st));
+    C.bits = (u32*)ar.take(C.L.bits_bytes);
+    C.canny_ws = ar.take(C.L.canny_bytes);
+    C.hough_ws = ar.take(C.L.hough_bytes);
+    C.blur_ws = ar.take(C.L.blur_ws_bytes);
+    C.blur_plane = (u8*)ar.take(C.L.blur_plane_bytes);
+    C.bpw = bits_pitch_words(width), C.bsw = C.bpw * (size_t)height;
+    C.tv = thresh_val < -1 ? -1 : (thresh_val > 256 ? 256 : thresh_val);
     // open with (1 x vert_len) and (horiz_len x 1), iterations folded into one larger kernel
-    const int KV = vert_len + (iterations - 1) * (vert_len - 1), AV = (vert_len / 2) * iterations;
-    const int KH = horiz_len + (iterations - 1) * (horiz_len - 1), AH = (horiz_len / 2) * iterations;
-    static int overlap = -1;  // IPA_OVERLAP=0: everything on the caller's stream
-    if (overlap < 0) {
-        const char* e = getenv("IPA_OVERLAP");
-        overlap = e ? atoi(e) : 1;
-    }
-    hipStream_t so = overlap && !g_prof_on ? side_stream(0) : nullptr;  // stream of the opens
-    hipEvent_t ev_gray = nullptr, ev_open = nullptr;
-    if (so) {
-        if (hipEventCreateWithFlags(&ev_gray, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_open, hipEventDisableTiming) != hipSuccess) {
-            if (ev_gray) (void)hipEventDestroy(ev_gray);
-            ev_gray = nullptr;
-            so = nullptr;
-        }
-    }
-    if (so) {
-        IPA_HIP(hipEventRecord(ev_gray, st));
-        IPA_HIP(hipStreamWaitEvent(so, ev_gray, 0));
-    } else {
-        so = st;
-    }
-    {
-        ProfScope ps(PROF_OPEN_V, so);
-        rc = launch_bitmorph(bits, bpw, bsw, V, width, height, batch, 0, 2, 1, KV, 0, AV, 255, nullptr, so);
-    }
-    if (!rc) {
-        ProfScope ps(PROF_OPEN_H, so);
-        rc = launch_bitmorph(bits, bpw, bsw, H, width, height, batch, 0, 2, KH, 1, AH, 0, 255, nullptr, so);
-    }
-    // join: whatever happens below, the caller's stream waits for the opens
-    struct Join {
-        hipStream_t st, so;
-        hipEvent_t a, b;
-        ~Join()
-        {
-            if (so != st) {
-                if (hipEventRecord(b, so) == hipSuccess) (void)hipStreamWaitEvent(st, b, 0);
-                (void)hipEventDestroy(a);
-                (void)hipEventDestroy(b);
-            }
-        }
-    } join = {st, so, ev_gray, ev_open};
-    if (rc) return rc;
-    Plane csrc = G;
-    if (blur5x5) {
-        Plane BL = mkplane(blur_plane, L.blur_pitch, L.blur_pitch * (size_t)height);
-        ProfScope ps(PROF_BLUR, st);
-        rc = launch_gauss5(G, BL, width, height, batch, blur_ws, L.blur_ws_bytes, st);
-        if (rc) return rc;
-        csrc = BL;
-    }
+    C.KV = vert_len + (iterations - 1) * (vert_len - 1), C.AV = (vert_len / 2) * iterations;
+    C.KH = horiz_len + (iterations - 1) * (horiz_len - 1), C.AH = (horiz_len / 2) * iterations;
     double lo = canny_lo, hi = canny_hi;
     if (lo > hi) { double t = lo; lo = hi; hi = t; }
-    // with a Hough stage behind it, Canny also emits the list of edge pixels
-    PointSink sink = {nullptr, 0, 0, nullptr};
+    C.lo = (int)floor(lo), C.hi = (int)floor(hi);
+    return IPA_OK;
+}
+
+// gray + THRESH_BINARY_INV plane + its bit plane, one pass over the BGR input
+int stage_gray(const Chunk& C, hipStream_t st)
+{
+    ProfScope ps(PROF_GRAY_THRESH, st);
+    return launch_bgr2gray(C.B, C.G, C.T, C.bits, C.bpw, C.bsw, C.width, C.height, C.batch, C.tv, 255, 1, st);
+}
+
+int stage_opens(const Chunk& C, hipStream_t st)
+{
+    int rc;
+    {
+        ProfScope ps(PROF_OPEN_V, st);
+        rc = launch_bitmorph(C.bits, C.bpw, C.bsw, C.V, C.width, C.height, C.batch, 0, 2, 1, C.KV, 0, C.AV, 255, nullptr, st);
+    }
+    if (rc) return rc;
+    ProfScope ps(PROF_OPEN_H, st);
+    return launch_bitmorph(C.bits, C.bpw, C.bsw, C.H, C.width, C.height, C.batch, 0, 2, C.KH, 1, C.AH, 0, 255, nullptr, st);
+}
+
+bool fused_points()
+{
     static int fused = -1;  // IPA_FUSED_POINTS=1: the Canny kernels emit the edge-pixel list themselves (default: a
                             // separate compaction pass over the edge plane, which measures faster end to end)
     if (fused < 0) {
         const char* e = getenv("IPA_FUSED_POINTS");
         fused = e ? atoi(e) : 0;
     }
-    if (accum && fused) {
-        sink = hough_point_sink(width, height, max_points, point_counts, hough_ws);
-        IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+    return fused != 0;
+}
+
+// [GaussianBlur] + Canny; with a Hough stage behind it also the lists of edge pixels
+int stage_edges(const Chunk& C, bool with_lists, hipStream_t st)
+{
+    int rc;
+    Plane csrc = C.G;
+    if (C.blur5x5) {
+        Plane BL = mkplane(C.blur_plane, C.L.blur_pitch, C.L.blur_pitch * (size_t)C.height);
+        ProfScope ps(PROF_BLUR, st);
+        rc = launch_gauss5(C.G, BL, C.width, C.height, C.batch, C.blur_ws, C.L.blur_ws_bytes, st);
+        if (rc) return rc;
+        csrc = BL;
     }
-    rc = run_canny(csrc, E, width, height, batch, (int)floor(lo), (int)floor(hi), canny_ws, L.canny_bytes, sink, st);
+    PointSink sink = {nullptr, 0, 0, nullptr};
+    if (C.accum && fused_points()) {
+        sink = hough_point_sink(C.width, C.height, C.max_points, C.point_counts, C.hough_ws);
+        IPA_HIP(hipMemsetAsync(C.point_counts, 0, sizeof(int32_t) * (size_t)C.batch, st));
+    }
+    rc = run_canny(csrc, C.E, C.width, C.height, C.batch, C.lo, C.hi, C.canny_ws, C.L.canny_bytes, sink, st);
+    if (rc || !C.accum || !with_lists || fused_points()) return rc;
+    return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
+                           C.point_counts, C.hough_ws, C.L.hough_bytes, HOUGH_COMPACT_ONLY, 0, st);
+}
+
+// lists_ready: stage_edges has already made the edge-pixel lists
+int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t st)
+{
+    if (!C.accum) return IPA_OK;
+    return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
+                           C.point_counts, C.hough_ws, C.L.hough_bytes,
+                           (lists_ready || fused_points()) ? HOUGH_VOTE_ONLY : HOUGH_ALL, resident_wgs, st);
+}
+
+struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events()
+    {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+    hipEvent_t make()
+    {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        ev.push_back(e);
+        return e;
+    }
+};
+
+// a -> b: everything queued on b from now on waits for what is queued on a so far
+int stream_after(hipStream_t b, hipStream_t a, Events& E)
+{
+    hipEvent_t e = E.make();
+    IPA_REQUIRE(e != nullptr, IPA_ERR_HIP, "front_end: hipEventCreate failed");
+    IPA_HIP(hipEventRecord(e, a));
+    IPA_HIP(hipStreamWaitEvent(b, e, 0));
+    return IPA_OK;
+}
+
+// Holds its stream back for about `ticks` of the 100 MHz wall clock (bounded): gives a kernel that
+// was just queued on another stream time to get its workgroups onto the CUs first.
+__global__ void k_head_start(unsigned ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
+// One chunk, stage after stage on the caller's stream; the opens on a helper stream beside Canny.
+static int front_end_chunk(const Chunk& C, hipStream_t st, hipEvent_t after_gray = nullptr)
+{
+    int rc = stage_gray(C, st);
     if (rc) return rc;
-    if (accum)
-        rc = run_hough_accum(E, width, height, batch, 1.0, M_PI / 180, accum, accum_stride, seg_max, max_points, point_counts,
-                             hough_ws, L.hough_bytes, fused != 0, st);
+    if (after_gray) IPA_HIP(hipEventRecord(after_gray, st));
+    static int overlap = -1;  // IPA_OVERLAP=0: everything on the caller's stream
+    if (overlap < 0) {
+        const char* e = getenv("IPA_OVERLAP");
+        overlap = e ? atoi(e) : 1;
+    }
+    hipStream_t so = overlap && !g_prof_on ? side_stream(0) : nullptr;  // stream of the opens
+    Events E;
+    if (so && stream_after(so, st, E) != IPA_OK) so = nullptr;
+    if (!so) so = st;
+    rc = stage_opens(C, so);
+    if (!rc) rc = stage_edges(C, false, st);
+    if (!rc) rc = stage_vote(C, false, 0, st);
+    // join, also after an error: the caller's stream waits for the opens
+    if (so != st && stream_after(st, so, E) != IPA_OK) {
+        (void)hipStreamSynchronize(so);
+        if (!rc) rc = IPA_ERR_HIP;
+    }
     return rc;
 }
 
@@ -317,53 +380,94 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     hipStream_t st = (hipStream_t)stream;
     const int k = pipeline_chunks(batch);
     hipStream_t s2 = k > 1 ? side_stream(1) : nullptr;
-    if (!s2)
-        return front_end_chunk(bgr, bgr_pitch, bgr_stride, gray, thresh, vlines, hlines, edges, plane_pitch, plane_stride,
-                               accum, accum_stride, seg_max, max_points, point_counts, width, height, batch, thresh_val,
-                               vert_len, horiz_len, iterations, canny_lo, canny_hi, blur5x5, ws, ws_bytes, st);
-    hipEvent_t ev[IPA_MAX_CHUNKS + 1] = {};
-    int rc = IPA_OK;
-    for (int c = 0; c <= k && !rc; c++)
-        if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) {
-            ipa_set_error("front_end: hipEventCreate failed");
-            rc = IPA_ERR_HIP;
-        }
+    const int nk = s2 ? k : 1;
     int na = 0, nr = 0;
     if (accum) ipa_hough_dims(width, height, 1.0, M_PI / 180, &na, &nr);
     const size_t seg_stride = accum ? (size_t)na * hough_segments(nr) : 0;
-    // the helper stream starts behind the work already queued on the caller's stream
-    if (!rc && (hipEventRecord(ev[k], st) != hipSuccess || hipStreamWaitEvent(s2, ev[k], 0) != hipSuccess)) rc = IPA_ERR_HIP;
+    Chunk C[IPA_MAX_CHUNKS];
     size_t ws_off = 0;
-    bool used_s2 = false;
-    for (int c = 0; c < k && !rc; c++) {
-        int lo, hi;
-        chunk_range(batch, k, c, &lo, &hi);
-        hipStream_t sc = (c & 1) ? s2 : st;
-        // chunk c starts when the gray kernel of chunk c-1 (on the other stream) is done
-        if (c > 0 && hipStreamWaitEvent(sc, ev[c - 1], 0) != hipSuccess) {
-            rc = IPA_ERR_HIP;
-            break;
-        }
-        const size_t wsc = align_up(chunk_ws_bytes(width, height, hi - lo, max_points), 256);
-        used_s2 |= (c & 1) != 0;
-        rc = front_end_chunk(bgr + (size_t)lo * bgr_stride, bgr_pitch, bgr_stride, gray + (size_t)lo * plane_stride,
-                             thresh + (size_t)lo * plane_stride, vlines + (size_t)lo * plane_stride,
-                             hlines + (size_t)lo * plane_stride, edges + (size_t)lo * plane_stride, plane_pitch, plane_stride,
-                             accum ? accum + (size_t)lo * accum_stride : nullptr, accum_stride,
-                             seg_max ? seg_max + (size_t)lo * seg_stride : nullptr, max_points,
-                             point_counts ? point_counts + lo : nullptr, width, height, hi - lo, thresh_val, vert_len,
-                             horiz_len, iterations, canny_lo, canny_hi, blur5x5, (u8*)ws + ws_off, wsc, sc, ev[c]);
+    for (int c = 0; c < nk; c++) {
+        int lo = 0, hi = batch;
+        if (nk > 1) chunk_range(batch, nk, c, &lo, &hi);
+        const size_t wsc = nk > 1 ? align_up(chunk_ws_bytes(width, height, hi - lo, max_points), 256) : ws_bytes;
+        int rc = chunk_init(C[c], bgr + (size_t)lo * bgr_stride, bgr_pitch, bgr_stride, gray + (size_t)lo * plane_stride,
+                            thresh + (size_t)lo * plane_stride, vlines + (size_t)lo * plane_stride,
+                            hlines + (size_t)lo * plane_stride, edges + (size_t)lo * plane_stride, plane_pitch, plane_stride,
+                            accum ? accum + (size_t)lo * accum_stride : nullptr, accum_stride,
+                            seg_max ? seg_max + (size_t)lo * seg_stride : nullptr, max_points,
+                            point_counts ? point_counts + lo : nullptr, width, height, hi - lo, thresh_val, vert_len,
+                            horiz_len, iterations, canny_lo, canny_hi, blur5x5, (u8*)ws + ws_off, wsc);
+        if (rc) return rc;
         ws_off += wsc;
     }
+    if (nk == 1) return front_end_chunk(C[0], st);
+
+    Events E;
+    int rc = stream_after(s2, st, E);  // the helper stream starts behind the work already queued on the caller's stream
+    if (rc) return rc;
+    static int phased = -1;  // IPA_PHASED=0: the staggered schedule also when there is a Hough stage
+    if (phased < 0) {
+        const char* e = getenv("IPA_PHASED");
+        phased = e ? atoi(e) : 1;
+    }
+    if (accum && phased) {
+        // The vote of chunk c (LDS atomics) runs beside the binarisation of chunk c+1 (HBM): it is
+        // launched first, as one workgroup per CU that stays until all its work is done, and the
+        // streaming kernels fill the other half of every CU.  Launched the other way round the
+        // streaming kernels' small workgroups would keep refilling the CUs and the vote's large ones
+        // would wait.  The Canny stage (which wants the whole chip) follows when both are done.
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 0;
+        cus &= ~7;
+        static int head_ticks = -1;  // IPA_HEAD_START: head start of the vote kernel in 10 ns ticks
+        if (head_ticks < 0) {
+            const char* e = getenv("IPA_HEAD_START");
+            head_ticks = e ? atoi(e) : 3000;
+        }
+        rc = stage_gray(C[0], st);
+        if (!rc) rc = stream_after(s2, st, E);
+        if (!rc) rc = stage_opens(C[0], s2);
+        for (int c = 0; c < nk && !rc; c++) {
+            rc = stage_edges(C[c], true, st);
+            if (rc) break;
+            const bool more = c + 1 < nk;
+            if (more) {
+                rc = stream_after(s2, st, E);
+                if (rc) break;
+                hipLaunchKernelGGL(k_head_start, dim3(1), dim3(1), 0, s2, (unsigned)head_ticks);
+            }
+            rc = stage_vote(C[c], true, more ? cus : 0, st);
+            if (rc || !more) break;
+            rc = stage_gray(C[c + 1], s2);
+            if (!rc) rc = stream_after(st, s2, E);  // the next Canny needs this gray plane, not the opens
+            if (!rc) rc = stage_opens(C[c + 1], s2);
+        }
+    } else {
+        // Chunks alternate between the two streams, each starting when the previous chunk's gray
+        // kernel is done: the chunks stay one stage apart.
+        hipEvent_t prev = nullptr;
+        for (int c = 0; c < nk && !rc; c++) {
+            hipStream_t sc = (c & 1) ? s2 : st;
+            if (prev && hipStreamWaitEvent(sc, prev, 0) != hipSuccess) {
+                rc = IPA_ERR_HIP;
+                break;
+            }
+            prev = E.make();
+            if (!prev) {
+                rc = IPA_ERR_HIP;
+                break;
+            }
+            rc = front_end_chunk(C[c], sc, prev);
+        }
+    }
     // join, also after an error: the caller's stream must not run ahead of the helper stream
-    if (used_s2 && ev[k] && (hipEventRecord(ev[k], s2) != hipSuccess || hipStreamWaitEvent(st, ev[k], 0) != hipSuccess)) {
+    if (stream_after(st, s2, E) != IPA_OK) {
         (void)hipStreamSynchronize(s2);
         if (!rc) {
             ipa_set_error("front_end: joining the helper stream failed");
             rc = IPA_ERR_HIP;
         }
     }
-    for (int c = 0; c <= k; c++)
-        if (ev[c]) (void)hipEventDestroy(ev[c]);
     return rc;
 }

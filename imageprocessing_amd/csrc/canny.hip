@@ -755,11 +755,12 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
             const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;
             IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
+            static const size_t pad = lds_pad_kib("IPA_PAD_CANNY");
             if (sink.pts)
-                hipLaunchKernelGGL(k_canny_stream<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h,
+                hipLaunchKernelGGL(k_canny_stream<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), pad, st, src, dst, w, h,
                                    strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
             else
-                hipLaunchKernelGGL(k_canny_stream<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h,
+                hipLaunchKernelGGL(k_canny_stream<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), pad, st, src, dst, w, h,
                                    strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
         } else {
             IPA_REQUIRE(!sink.pts, IPA_ERR_ARG, "Canny: the LDS tile kernel cannot emit the edge-pixel list");

@@ -70,6 +70,15 @@ static inline bool plane_ok(const Plane& pl, size_t row_bytes, int batch)
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// Extra dynamic LDS (KiB, from the environment) requested at a launch: caps how many workgroups of
+// that kernel fit on a CU, which leaves room for a kernel of another stream to run beside it.
+static inline size_t lds_pad_kib(const char* env)
+{
+    const char* e = getenv(env);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (size_t)v * 1024 : 0;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Grid for a flat streaming kernel: enough blocks to fill 256 CUs several times
@@ -169,6 +178,10 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
 size_t hough_ws_bytes(int w, int h, int batch, int max_points);
 PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, void* ws);
 int hough_segments(int numrho);
+// phase: which part of the accumulator stage to enqueue.  resident_wgs > 0: the vote kernel runs as that
+// many workgroups (one per CU, each looping over its share of the work) so that it keeps half of every
+// CU while a streaming kernel of another stream uses the rest.
+enum HoughPhase { HOUGH_ALL = 0, HOUGH_VOTE_ONLY = 1, HOUGH_COMPACT_ONLY = 2 };
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                    int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready,
-                    hipStream_t st);
+                    int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
+                    int resident_wgs, hipStream_t st);

@@ -197,6 +197,7 @@ struct VoteArgs {
     int32_t* segmax;  // optional: per image, angle and 512-column segment the largest count
     int nsegs;        // segments per accumulator row
     int xcd_remap;    // 1: relabel workgroups so that an image's workgroups share an XCD
+    u32 items;        // k_hough_vote_s: (image, angle group) work items = groups * images of the launch
 };
 
 __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
@@ -207,6 +208,9 @@ __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
 constexpr int VOTE_THREADS = 512;
 constexpr int HOUGH_SEG = VOTE_THREADS;  // columns per segment of the per-row maxima
 constexpr int VOTE_MAX_TG = 16;
+#ifndef VOTE_PREFETCH
+#define VOTE_PREFETCH 2
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -349,15 +353,19 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 // workgroup: every workgroup streams the image's whole point list (from L2), so more angles per
 // workgroup mean less list traffic, and 1024 threads keep the CU full with two such workgroups.
 template <int TG, int NT>
-__global__ __launch_bounds__(NT) void k_hough_vote_s(VoteArgs A, Trig T)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))  // two 1024-thread workgroups per CU
+void k_hough_vote_s(VoteArgs A, Trig T)
 {
     extern __shared__ __align__(16) u32 hist[];
     const int tid = threadIdx.x;
     // all workgroups of one image (they stream the same point list) on one XCD
-    const u32 wg = A.xcd_remap ? xcd_contiguous_id(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y)
-                               : blockIdx.x + blockIdx.y * gridDim.x;
-    const int b = (int)(wg / gridDim.x);
-    const int grp = (int)(wg - (u32)b * gridDim.x);
+    // The grid is one-dimensional and may be smaller than the number of work items (a resident
+    // grid that keeps its share of every CU while kernels of other streams come and go); its size is
+    // a multiple of 8 then, so that a workgroup's items stay on its XCD.
+  for (u32 item = blockIdx.x; item < A.items; item += gridDim.x) {
+    const u32 wg = A.xcd_remap ? xcd_contiguous_id(item, A.items) : item;
+    const int b = (int)(wg / (u32)A.groups);
+    const int grp = (int)(wg - (u32)b * (u32)A.groups);
     const int n0 = grp * TG;
     const int tg = min(TG, A.numangle - n0);
     const int half = (A.numrho - 1) / 2;
@@ -390,17 +398,13 @@ __global__ __launch_bounds__(NT) void k_hough_vote_s(VoteArgs A, Trig T)
     const u32 nfull = npts >> 2;
     char* const hb = (char*)hist;
     const f2 magic = {12582912.0f, 12582912.0f};
-    // four consecutive list entries per lane and trip (one 16-byte load), next trip prefetched
-    const u32 tail0 = nfull * 4;
+    // Four consecutive list entries per lane and trip (one 16-byte load).  The loads run PF trips
+    // ahead of the votes: the list comes from L2 when the workgroup has the chip to itself, but
+    // from a busy HBM when a streaming kernel of another stream shares the CU.
+    constexpr int PF = VOTE_PREFETCH;
+    const u32 trips = nfull / NT;  // trips in which every lane has four points
     auto load4 = [&](u32 trip) -> uint4 { return pts4[trip * NT + tid]; };
-    auto valid = [&](u32 trip) -> bool { return trip * NT + tid < nfull; };
-    u32 i = 0;
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (valid(0)) cur = load4(0);
-    while (valid(i)) {
-        const u32 inext = i + 1;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (valid(inext)) nxt = load4(inext);
+    auto cast4 = [&](const uint4 cur) {
         const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
         const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
         const f2 y01 = {(float)(cur.x >> 16), (float)(cur.y >> 16)};
@@ -416,9 +420,26 @@ __global__ __launch_bounds__(NT) void k_hough_vote_s(VoteArgs A, Trig T)
                 atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.y) << 2) + k4[g])), 1u);
             }
         }
-        cur = nxt;
-        i = inext;
+    };
+    if (trips) {
+        uint4 buf[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) buf[k] = load4(min((u32)k, trips - 1));
+        u32 i = 0;
+        for (; i + PF <= trips; i += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const uint4 cur = buf[k];
+                buf[k] = load4(min(i + PF + k, trips - 1));  // past the end: the last trip again, never used
+                cast4(cur);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++)
+            if (i + k < trips) cast4(buf[k]);
     }
+    if (trips * NT + tid < nfull) cast4(load4(trips));
+    const u32 tail0 = nfull * 4;
     // the points left over by the four-at-a-time loop
     for (u32 j = tail0 + tid; j < npts; j += NT) {
         const u32 p = pts[j];
@@ -466,6 +487,8 @@ __global__ __launch_bounds__(NT) void k_hough_vote_s(VoteArgs A, Trig T)
         for (int col = tid; col < ncols; col += NT) acc[col] = 0;
     if (grp == A.groups - 1)
         for (int col = tid; col < ncols; col += NT) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
+    __syncthreads();  // the bins are cleared again for the next item
+  }
 }
 
 // Four cells per lane and trip (independent loads); the four neighbours are read only for
@@ -617,13 +640,14 @@ PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, 
     return k;
 }
 
-// `points_ready`: the per-image point lists (layout of hough_point_sink) and point_counts were
-// already produced by the Canny kernels; otherwise they are compacted from `src` here.
+// phase HOUGH_VOTE_ONLY: the per-image point lists (layout of hough_point_sink) and point_counts
+// already exist (made by the Canny kernels or by an earlier HOUGH_COMPACT_ONLY call); otherwise they
+// are compacted from `src` here.
 int hough_segments(int numrho) { return cdiv(numrho + 2, HOUGH_SEG); }
 
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
-                    int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, bool points_ready,
-                    hipStream_t st)
+                    int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
+                    int resident_wgs, hipStream_t st)
 {
     IPA_REQUIRE(w <= 65535 && h <= 65535, IPA_ERR_ARG, "HoughLines: image larger than 65535 pixels on a side");
     int numangle, numrho;
@@ -649,7 +673,8 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             T.c[n] = (float)(cos((double)ang) * irho);
         }
     }
-    if (!points_ready) {
+    static const bool revote = getenv("IPA_VOTE_ONLY") != nullptr;  // experiments: re-vote the lists of the previous call
+    if (phase != HOUGH_VOTE_ONLY && !revote) {
         IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
         ProfScope ps(PROF_HOUGH_COMPACT, st);
         const int cpr = cdiv(w, 16);
@@ -665,7 +690,8 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
                 const char* e = getenv("IPA_COMPACT_SPREAD");
                 spread = e ? atoi(e) : 1;
             }
-            hipLaunchKernelGGL(k_hough_compact2, grid, rows_block(), 0, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
+            static const size_t pad = lds_pad_kib("IPA_PAD_COMPACT");
+            hipLaunchKernelGGL(k_hough_compact2, grid, rows_block(), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
             IPA_LAUNCH_CHECK();
         } else {
             IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL - (1 << 22), IPA_ERR_ARG, "HoughLines: image too large");
@@ -684,6 +710,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             }
         }
     }
+    if (phase == HOUGH_COMPACT_ONLY) return IPA_OK;
     // geometry of the vote kernel
     VoteArgs A;
     A.pts = pts; A.pts_stride = pts_stride; A.cap = cap; A.counts = point_counts;
@@ -764,7 +791,9 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     A.segmax = tgs ? seg_max : nullptr;
     if (seg_max && !tgs)  // this kernel variant does not produce the maxima: mark every segment as worth reading
         IPA_HIP(hipMemsetD32Async((hipDeviceptr_t)seg_max, 0x7fffffff, (size_t)batch * numangle * A.nsegs, st));
-    size_t lds = (size_t)tg * span_words * 4;
+    size_t lds = (size_t)tg * span_words * 4 + lds_pad_kib("IPA_PAD_VOTE");
+    // a resident grid must not get two workgroups onto one CU: more than half of the CU's LDS each
+    if (resident_wgs > 0 && lds < 81 * 1024) lds = 81 * 1024;
     if (lds > 48 * 1024 && !g_vote_attr_set) {
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -789,12 +818,20 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.accum = accum + (size_t)b0 * accum_stride;
         if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
+        Ab.items = (u32)A.groups * (u32)nb;
+        static int resident_env = -1;  // IPA_VOTE_RESIDENT: force a resident grid of that many workgroups (multiple of 8)
+        if (resident_env < 0) {
+            const char* e = getenv("IPA_VOTE_RESIDENT");
+            resident_env = e ? atoi(e) : 0;
+        }
+        const int resident = (resident_env > 0 ? resident_env : resident_wgs) & ~7;
+        const dim3 grid_s(resident > 0 && (u32)resident < Ab.items ? (unsigned)resident : Ab.items);
 #define IPA_VOTE_S(TGV)                                                                               \
     do {                                                                                              \
         if (vote_nt == 1024)                                                                          \
-            hipLaunchKernelGGL((k_hough_vote_s<TGV, 1024>), grid, dim3(1024), lds, st, Ab, T);         \
+            hipLaunchKernelGGL((k_hough_vote_s<TGV, 1024>), grid_s, dim3(1024), lds, st, Ab, T);       \
         else                                                                                          \
-            hipLaunchKernelGGL((k_hough_vote_s<TGV, 512>), grid, dim3(512), lds, st, Ab, T);           \
+            hipLaunchKernelGGL((k_hough_vote_s<TGV, 512>), grid_s, dim3(512), lds, st, Ab, T);         \
     } while (0)
         if (tgs == 8) IPA_VOTE_S(8);
         else if (tgs == 4) IPA_VOTE_S(4);
@@ -844,7 +881,7 @@ IPA_EXPORT int ipa_hough_accum_u8(const uint8_t* src, size_t src_pitch, size_t s
     IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
                 "HoughLines: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
     return run_hough_accum(s, width, height, batch, rho, theta, accum, accum_stride, seg_max, max_points, point_counts,
-                           ws, ws_bytes, false, st);
+                           ws, ws_bytes, HOUGH_ALL, 0, st);
 }
 
 IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, const int32_t* seg_max, int numangle,

@@ -710,7 +710,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
             Plane db = dst;
             db.p += (size_t)b0 * dst.stride;
 #define IPA_H3(N, K, A)                                                                                          \
-    hipLaunchKernelGGL((k_bitmorph_h3<N, K, A>), rows_grid(words, h, nb), rows_block(), 0, st, bits + (size_t)b0 * bsw, \
+    hipLaunchKernelGGL((k_bitmorph_h3<N, K, A>), rows_grid(words, h, nb), rows_block(), lds_pad_kib("IPA_PAD_MORPH"), st, bits + (size_t)b0 * bsw, \
                        bpw, bsw, db, w, h, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value,                   \
                        value_dev ? value_dev + b0 : nullptr)
             // the shapes of the parsers (15-pixel lines, 1 or 2 iterations) and of 3x3 open / close
@@ -737,7 +737,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
             db.p += (size_t)b0 * dst.stride;
             const dim3 grid((unsigned)cdiv(words, 64), (unsigned)cdiv(strips, 4), (unsigned)nb), block(64, 4);
             if (ky < 32)
-                hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, 0, st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
+                hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, lds_pad_kib("IPA_PAD_MORPH"), st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
                                    strips, strip_rows, first_is_dilate, nops, ky, ay, (u32)value,
                                    value_dev ? value_dev + b0 : nullptr);
             else

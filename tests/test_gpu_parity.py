@@ -431,6 +431,19 @@ def test_front_end_batch_matches_single():
         _check_front_end(single, batch[i], 128, 15, 15, 2, 50, 150, False)
 
 
+@pytest.mark.parametrize("n,hough", [(70, True), (131, True), (70, False)])
+def test_front_end_large_batch_runs_in_chunks(n, hough):
+    # batches of 64 images and more are cut into chunks of at least 32 that overlap on two streams
+    # (with a Hough stage: the vote of one chunk beside the binarisation of the next)
+    h, w = 72, 112
+    batch = np.stack([uml_like(3000 + i, h, w, noise=(3 if i % 3 == 0 else 0)) for i in range(n)])
+    res = cv2.front_end_batch(batch, thresh_val=140, hough=hough)
+    for i in range(n):
+        single = cv2.FrontEndResult(res.gray[i], res.thresh[i], res.vlines[i], res.hlines[i], res.edges[i],
+                                    res.accum[i] if hough else None)
+        _check_front_end(single, batch[i], 140, 15, 15, 2, 50, 150, False)
+
+
 def test_front_end_1080p_config1():
     # BASELINE config 1: one 1920x1080 class-diagram raster, seed 1000, 12 boxes
     bgr = uml_like(1000, 1080, 1920)
