@@ -56,6 +56,9 @@ SIGNATURES = {
     "ipa_hough_peaks_i32": (_i, [_vp, _sz, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ipa_segments_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ipa_segments_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ipa_hough_lines_p_dims": (_i, [_i, _i, _d, _d, _vp, _vp]),
+    "ipa_hough_lines_p_workspace_bytes": (_sz, [_i, _i, _i, _d, _d, _i]),
+    "ipa_hough_lines_p_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _d, _d, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "ipa_front_end_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ipa_front_end_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _i, _vp,
                               _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _sz, _vp]),

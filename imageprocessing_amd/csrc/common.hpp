@@ -153,6 +153,31 @@ int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bits_pit
 
 // bit-plane geometry: words per row rounded to a multiple of 32 (one 128-byte cache line), so
 // that the 128-byte pieces the producing waves write never share a line between workgroups
+// Inclusive scan of one value per thread over a 1024-thread workgroup (16 waves): shuffles inside
+// the wave, the 16 wave totals through LDS.  Two barriers; s_wave must hold 16 words.
+__device__ __forceinline__ u32 block_scan_1024(u32 v, u32* s_wave, u32& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 scan = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)scan, o);
+        if (lane >= o) scan += t;
+    }
+    __syncthreads();  // s_wave may still be read by the previous round
+    if (lane == 63) s_wave[wv] = scan;
+    __syncthreads();
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 t = s_wave[k];
+        before += k < wv ? t : 0u;
+        all += t;
+    }
+    total = all;
+    return scan + before;
+}
+
 static inline size_t bits_pitch_words(int w) { return align_up((size_t)cdiv(w, 32), 32); }
 
 int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, hipStream_t st);

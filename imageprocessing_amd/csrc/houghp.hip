@@ -1,0 +1,393 @@
+// cv2.HoughLinesP (progressive probabilistic Hough transform) on the device: lineDetection.py:12-19,
+// "New Version/comparison.py":14, newVersion3/detectHorizontalVerticalLines.py:64 and three more
+// scripts of the reference.
+//
+// The algorithm is sequential by construction: the non-zero pixels are visited in a pseudo-random
+// order (cv::RNG, multiply-with-carry), each visit reads and changes the accumulator and the pixel
+// mask, and a found segment removes its pixels before the next visit.  One WAVE therefore owns one
+// image and runs the visits in order; inside a visit the 64 lanes share the work (angles of a vote,
+// steps of a line walk), and a batch of images runs as many waves side by side.
+//
+//   k_hp_rowcount / k_hp_scan / k_hp_fill   non-zero pixels as a list in raster order (the order
+//                                           the random draws index into) from the 1-bit plane
+//   k_hp_run                                 the visits; the bit plane is the mask
+#include "common.hpp"
+
+#include <math.h>
+
+int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, int32_t* vmax, hipStream_t st);
+
+namespace {
+
+constexpr int HP_MAX_ANGLES = 448;
+struct HpTrig {
+    float c[HP_MAX_ANGLES];
+    float s[HP_MAX_ANGLES];
+};
+
+struct HpArgs {
+    u32* bits;  // [batch][h][bpw] mask, one bit per pixel
+    size_t bpw, bsw;
+    u32* rowcnt;   // [batch][h]
+    u32* rowoff;   // [batch][h + 1]
+    int32_t* total;  // [batch] non-zero pixels, -1: more than cap
+    u32* nz;       // [batch][cap] (y << 16) | x
+    u32 cap;
+    int32_t* accum;  // [batch][numangle][numrho]
+    size_t accum_stride;
+    int w, h, numangle, numrho, threshold, line_length, line_gap;
+    int32_t* lines;  // [batch][max_lines][4]
+    int max_lines;
+    int32_t* counts;  // [batch] segments found (may exceed max_lines), -1: list capacity exceeded
+};
+
+// one wave per row
+__global__ __launch_bounds__(256) void k_hp_rowcount(HpArgs A)
+{
+    const int b = blockIdx.y;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= A.h) return;
+    const int lane = threadIdx.x & 63;
+    const int words = (A.w + 31) >> 5;
+    const u32* row = A.bits + (size_t)b * A.bsw + (size_t)y * A.bpw;
+    u32 n = 0;
+    for (int j = lane; j < words; j += 64) n += __popc(row[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += (u32)__shfl_xor((int)n, o);
+    if (lane == 0) A.rowcnt[(size_t)b * A.h + y] = n;
+}
+
+__global__ __launch_bounds__(1024) void k_hp_scan(HpArgs A)
+{
+    __shared__ u32 s_wave[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const u32* cnt = A.rowcnt + (size_t)b * A.h;
+    u32* off = A.rowoff + (size_t)b * (A.h + 1);
+    u32 base = 0;
+    for (int y0 = 0; y0 < A.h; y0 += 1024) {
+        const int y = y0 + tid;
+        const u32 c = y < A.h ? cnt[y] : 0u;
+        u32 total;
+        const u32 incl = block_scan_1024(c, s_wave, total);
+        if (y < A.h) off[y] = base + incl - c;
+        base += total;
+    }
+    if (tid == 0) {
+        off[A.h] = base;
+        A.total[b] = base > A.cap ? -1 : (int32_t)base;
+    }
+}
+
+// one wave per row: the row's non-zero pixels, left to right
+__global__ __launch_bounds__(256) void k_hp_fill(HpArgs A)
+{
+    const int b = blockIdx.y;
+    if (A.total[b] < 0) return;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= A.h) return;
+    const int lane = threadIdx.x & 63;
+    const int words = (A.w + 31) >> 5;
+    const u32* row = A.bits + (size_t)b * A.bsw + (size_t)y * A.bpw;
+    u32* out = A.nz + (size_t)b * A.cap;
+    u32 k = A.rowoff[(size_t)b * (A.h + 1) + y];
+    for (int j0 = 0; j0 < words; j0 += 64) {
+        const int j = j0 + lane;
+        u32 t = j < words ? row[j] : 0u;
+        const u32 c = __popc(t);
+        u32 scan = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = (u32)__shfl_up((int)scan, o);
+            if (lane >= o) scan += v;
+        }
+        u32 pos = k + scan - c;
+        while (t) {
+            const int i = __ffs(t) - 1;
+            t &= t - 1;
+            out[pos++] = ((u32)y << 16) | (u32)(32 * j + i);
+        }
+        k += (u32)__shfl((int)scan, 63);
+    }
+}
+
+__device__ __forceinline__ u32 ld_l2(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_l2(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int hp_rho(int x, int y, float c, float s)
+{
+    return __float2int_rn(__fadd_rn(__fmul_rn((float)x, c), __fmul_rn((float)y, s)));
+}
+
+// One wave per image.  Everything that steers control flow is wave-uniform.
+__global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int count = A.total[b];
+    if (count < 0) {
+        if (lane == 0) A.counts[b] = -1;
+        return;
+    }
+    u32* const bits = A.bits + (size_t)b * A.bsw;
+    u32* const nz = A.nz + (size_t)b * A.cap;
+    int32_t* const acc = A.accum + (size_t)b * A.accum_stride;
+    int32_t* const lines = A.lines + (size_t)b * A.max_lines * 4;
+    const int w = A.w, h = A.h, numangle = A.numangle, numrho = A.numrho, half = (numrho - 1) / 2;
+    const int shift = 16;
+    auto mask_at = [&](int i1, int j1) -> u32 { return (ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) >> (j1 & 31)) & 1u; };
+    unsigned long long rng = 0xffffffffffffffffULL;
+    int nlines = 0;
+    for (; count > 0; count--) {
+        rng = (unsigned long long)(u32)rng * 4164903690ULL + (u32)(rng >> 32);
+        const u32 idx = (u32)rng % (u32)count;
+        // draw without replacement: the last entry takes the drawn entry's place
+        const u32 p = ld_l2(&nz[idx]);
+        const u32 last = ld_l2(&nz[count - 1]);
+        if (lane == 0) st_l2(&nz[idx], last);
+        const int i = (int)(p >> 16), j = (int)(p & 0xffffu);
+        if (!mask_at(i, j)) continue;  // already part of a segment
+
+        // vote; the winner is the first angle whose bin holds the largest count
+        int best_val = -1, best_n = 0;
+        for (int n = lane; n < numangle; n += 64) {
+            const int r = hp_rho(j, i, T.c[n], T.s[n]) + half;
+            const int val = atomicAdd(&acc[(size_t)n * numrho + r], 1) + 1;
+            if (val > best_val) {
+                best_val = val;
+                best_n = n;
+            }
+        }
+        unsigned long long key = ((unsigned long long)(u32)(best_val + 1) << 32) | (u32)(0x7fffffff - best_n);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other > key ? other : key;
+        }
+        const int max_val = (int)(key >> 32) - 1, max_n = 0x7fffffff - (int)(u32)key;
+        if (max_val < A.threshold) continue;
+
+        // direction of the line and its 16.16 fixed-point step
+        const float a = -T.s[max_n], bb = T.c[max_n];
+        int x0 = j, y0 = i, dx0, dy0;
+        bool xflag;
+        if (fabsf(a) > fabsf(bb)) {
+            xflag = true;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = __float2int_rn(__fdiv_rn(__fmul_rn(bb, 65536.0f), fabsf(a)));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = false;
+            dy0 = bb > 0 ? 1 : -1;
+            dx0 = __float2int_rn(__fdiv_rn(__fmul_rn(a, 65536.0f), fabsf(bb)));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        auto pos_at = [&](int k, int t, int& i1, int& j1) {
+            const int x = x0 + (k ? -dx0 : dx0) * t, y = y0 + (k ? -dy0 : dy0) * t;
+            j1 = xflag ? x : x >> shift;
+            i1 = xflag ? y >> shift : y;
+        };
+
+        // first walk: how far the segment reaches in each direction (step index of its last pixel)
+        int last_step[2] = {0, 0};
+        for (int k = 0; k < 2; k++) {
+            int gap = 0;
+            bool stop = false;
+            for (int base = 0; !stop; base += 64) {
+                int i1, j1;
+                pos_at(k, base + lane, i1, j1);
+                const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                const bool on = inb && mask_at(i1, j1);
+                const unsigned long long M = __ballot(on), O = __ballot(!inb);
+                if (O == 0 && M == ~0ULL) {
+                    gap = 0;
+                    last_step[k] = base + 63;
+                    continue;
+                }
+                for (int t = 0; t < 64; t++) {
+                    if ((O >> t) & 1ULL) {
+                        stop = true;
+                        break;
+                    }
+                    if ((M >> t) & 1ULL) {
+                        gap = 0;
+                        last_step[k] = base + t;
+                    } else if (++gap > A.line_gap) {
+                        stop = true;
+                        break;
+                    }
+                }
+            }
+        }
+        int ex[2], ey[2];
+        pos_at(0, last_step[0], ey[0], ex[0]);
+        pos_at(1, last_step[1], ey[1], ex[1]);
+        const bool good = abs(ex[1] - ex[0]) >= A.line_length || abs(ey[1] - ey[0]) >= A.line_length;
+
+        // second walk: the segment's pixels leave the mask and, for a kept segment, take their votes
+        // back.  Step 0 (the drawn pixel itself) belongs to both directions; it is handled once.
+        for (int k = 0; k < 2; k++) {
+            for (int base = k; base <= last_step[k]; base += 64) {
+                int i1, j1;
+                const int t = base + lane;
+                pos_at(k, t, i1, j1);
+                const bool on = t <= last_step[k] && mask_at(i1, j1);
+                unsigned long long M = __ballot(on);
+                if (on) atomicAnd(&bits[(size_t)i1 * A.bpw + (j1 >> 5)], ~(1u << (j1 & 31)));
+                if (good) {
+                    while (M) {
+                        const int tt = base + (__ffsll((long long)M) - 1);
+                        M &= M - 1;
+                        int iu, ju;
+                        pos_at(k, tt, iu, ju);
+                        for (int n = lane; n < numangle; n += 64)
+                            atomicAdd(&acc[(size_t)n * numrho + hp_rho(ju, iu, T.c[n], T.s[n]) + half], -1);
+                    }
+                }
+            }
+        }
+        __threadfence();  // the next visit reads what this one changed
+        if (good) {
+            if (lane == 0 && nlines < A.max_lines) {
+                lines[4 * nlines + 0] = ex[0];
+                lines[4 * nlines + 1] = ey[0];
+                lines[4 * nlines + 2] = ex[1];
+                lines[4 * nlines + 3] = ey[1];
+            }
+            nlines++;
+        }
+    }
+    if (lane == 0) A.counts[b] = nlines;
+}
+
+void hp_dims(int w, int h, double rho, double theta, int* numangle, int* numrho)
+{
+    const float frho = (float)rho, ftheta = (float)theta;
+    int na = (int)floor((M_PI - 0.0) / ftheta) + 1;
+    if (na > 1 && fabs(M_PI - (na - 1) * ftheta) < ftheta / 2) --na;
+    *numangle = na;
+    *numrho = (int)lrintf(((w + h) * 2 + 1) / frho);
+}
+
+u32 hp_cap(int w, int h, int max_points)
+{
+    const long long full = (long long)w * h;
+    if (max_points > 0 && max_points < full) return (u32)max_points;
+    return (u32)(full > 0x7fffffffLL ? 0x7fffffffLL : full);
+}
+
+struct HpLayout {
+    size_t bits, vmax, rowcnt, rowoff, total, nz, accum, accum_stride;
+};
+size_t hp_layout(HpLayout& L, int w, int h, int batch, int numangle, int numrho, u32 cap, void* ws, size_t ws_bytes, u8** ptrs)
+{
+    Arena a(ws, ws_bytes);
+    L.accum_stride = align_up((size_t)numangle * numrho, 64);
+    const size_t sizes[7] = {bits_pitch_words(w) * 4 * (size_t)h * batch, sizeof(int32_t) * (size_t)batch,
+                             sizeof(u32) * (size_t)h * batch,             sizeof(u32) * ((size_t)h + 1) * batch,
+                             sizeof(int32_t) * (size_t)batch,             sizeof(u32) * (size_t)cap * batch,
+                             sizeof(int32_t) * L.accum_stride * batch};
+    for (int i = 0; i < 7; i++) {
+        u8* p = (u8*)a.take(sizes[i]);
+        if (ptrs) ptrs[i] = p;
+    }
+    return a.off + 256;
+}
+
+}  // namespace
+
+IPA_EXPORT int ipa_hough_lines_p_dims(int width, int height, double rho, double theta, int* numangle, int* numrho)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(rho > 0 && theta > 0, IPA_ERR_ARG, "HoughLinesP: rho and theta must be positive");
+    IPA_REQUIRE(numangle && numrho, IPA_ERR_ARG, "HoughLinesP: NULL output");
+    hp_dims(width, height, rho, theta, numangle, numrho);
+    return IPA_OK;
+}
+
+IPA_EXPORT size_t ipa_hough_lines_p_workspace_bytes(int width, int height, int batch, double rho, double theta, int max_points)
+{
+    if (width <= 0 || height <= 0 || batch <= 0 || !(rho > 0) || !(theta > 0)) return 0;
+    int na, nr;
+    hp_dims(width, height, rho, theta, &na, &nr);
+    if (na < 1 || nr < 1) return 0;
+    HpLayout L;
+    return hp_layout(L, width, height, batch, na, nr, hp_cap(width, height, max_points), nullptr, 0, nullptr);
+}
+
+IPA_EXPORT int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, int width, int height, int batch,
+                                    double rho, double theta, int threshold, int min_line_length, int max_line_gap,
+                                    int max_points, int32_t* lines, int max_lines, int32_t* counts, void* ws, size_t ws_bytes,
+                                    void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0 && max_lines >= 0, IPA_ERR_ARG, "HoughLinesP: negative size");
+    IPA_REQUIRE(rho > 0 && theta > 0, IPA_ERR_ARG, "HoughLinesP: rho and theta must be positive");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(counts != nullptr && (lines != nullptr || max_lines == 0), IPA_ERR_ARG, "HoughLinesP: NULL output");
+    hipStream_t st = (hipStream_t)stream;
+    if (width == 0 || height == 0) {
+        IPA_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)batch, st));
+        return IPA_OK;
+    }
+    IPA_REQUIRE(width <= 65535 && height <= 65535, IPA_ERR_ARG, "HoughLinesP: image larger than 65535 pixels on a side");
+    int na, nr;
+    hp_dims(width, height, rho, theta, &na, &nr);
+    IPA_REQUIRE(na >= 1 && na <= HP_MAX_ANGLES, IPA_ERR_ARG, "HoughLinesP: %d angles (theta too small; at most %d supported)", na,
+                HP_MAX_ANGLES);
+    IPA_REQUIRE(nr >= 1 && (long long)na * nr < 0x7fffffffLL, IPA_ERR_ARG, "HoughLinesP: accumulator too large");
+    Plane s = mkplane(src, src_pitch, src_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
+                "HoughLinesP: pointer/pitch must be 16-byte aligned and pitch >= row bytes");
+    IPA_REQUIRE(ws && ws_bytes >= ipa_hough_lines_p_workspace_bytes(width, height, batch, rho, theta, max_points),
+                IPA_ERR_WORKSPACE, "HoughLinesP: workspace too small");
+    HpLayout L;
+    u8* ptr[7];
+    const u32 cap = hp_cap(width, height, max_points);
+    hp_layout(L, width, height, batch, na, nr, cap, ws, ws_bytes, ptr);
+    HpArgs A;
+    A.bits = (u32*)ptr[0];
+    A.bpw = bits_pitch_words(width);
+    A.bsw = A.bpw * (size_t)height;
+    int32_t* vmax = (int32_t*)ptr[1];
+    A.rowcnt = (u32*)ptr[2];
+    A.rowoff = (u32*)ptr[3];
+    A.total = (int32_t*)ptr[4];
+    A.nz = (u32*)ptr[5];
+    A.cap = cap;
+    A.accum = (int32_t*)ptr[6];
+    A.accum_stride = L.accum_stride;
+    A.w = width; A.h = height; A.numangle = na; A.numrho = nr;
+    A.threshold = threshold; A.line_length = min_line_length; A.line_gap = max_line_gap;
+    A.lines = lines; A.max_lines = max_lines; A.counts = counts;
+    HpTrig T;
+    {
+        // cv::HoughLinesProbabilistic: trigtab[n] = (float)(cos((double)n * theta) / rho) with float rho, theta
+        const float frho = (float)rho, ftheta = (float)theta;
+        const float irho = 1 / frho;
+        for (int n = 0; n < na; n++) {
+            T.c[n] = (float)(cos((double)n * ftheta) * irho);
+            T.s[n] = (float)(sin((double)n * ftheta) * irho);
+        }
+        for (int n = na; n < HP_MAX_ANGLES; n++) T.c[n] = T.s[n] = 0.f;
+    }
+    int rc = launch_pack_bits(s, A.bits, A.bpw, A.bsw, width, height, batch, vmax, st);
+    if (rc) return rc;
+    IPA_HIP(hipMemsetAsync(A.accum, 0, sizeof(int32_t) * L.accum_stride * (size_t)batch, st));
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        HpArgs B = A;
+        B.bits += (size_t)b0 * A.bsw;
+        B.rowcnt += (size_t)b0 * height;
+        B.rowoff += (size_t)b0 * (height + 1);
+        B.total += b0;
+        B.nz += (size_t)b0 * cap;
+        B.accum += (size_t)b0 * L.accum_stride;
+        B.lines = lines ? lines + (size_t)b0 * max_lines * 4 : nullptr;
+        B.counts += b0;
+        const dim3 rows((unsigned)cdiv(height, 4), (unsigned)nb);
+        hipLaunchKernelGGL(k_hp_rowcount, rows, dim3(256), 0, st, B);
+        hipLaunchKernelGGL(k_hp_scan, dim3((unsigned)nb), dim3(1024), 0, st, B);
+        hipLaunchKernelGGL(k_hp_fill, rows, dim3(256), 0, st, B);
+        hipLaunchKernelGGL(k_hp_run, dim3((unsigned)nb), dim3(64), 0, st, B, T);
+        IPA_LAUNCH_CHECK();
+    }
+    return IPA_OK;
+}

@@ -69,31 +69,6 @@ __global__ __launch_bounds__(256) void k_seg_count(const u32* __restrict__ bits,
     if (lane == 0) A.rowcnt[(size_t)b * h + y] = n + 1;
 }
 
-// Inclusive scan of one value per thread over a 1024-thread workgroup (16 waves): shuffles inside
-// the wave, the 16 wave totals through LDS.  Two barriers; s_wave must hold 16 words.
-__device__ __forceinline__ u32 block_scan_1024(u32 v, u32* s_wave, u32& total)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    u32 scan = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 t = (u32)__shfl_up((int)scan, o);
-        if (lane >= o) scan += t;
-    }
-    __syncthreads();  // s_wave may still be read by the previous round
-    if (lane == 63) s_wave[wv] = scan;
-    __syncthreads();
-    u32 before = 0, all = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 t = s_wave[k];
-        before += k < wv ? t : 0u;
-        all += t;
-    }
-    total = all;
-    return scan + before;
-}
-
 // one workgroup per image: exclusive scan of the row counts
 __global__ __launch_bounds__(1024) void k_seg_scan(int h, SegArrays A)
 {

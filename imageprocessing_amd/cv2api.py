@@ -317,3 +317,46 @@ def HoughLines(image, rho, theta, threshold, lines=None, srn=0, stn=0, min_theta
         return None
     out = lines_from_keys(keys, acc.shape[1] - 2, rho, theta)
     return torch.from_numpy(out).to(acc.device) if _is_torch(image) else out
+
+
+def hough_lines_p_batch(images, rho, theta, threshold, minLineLength=0, maxLineGap=0, max_lines=4096):
+    """cv2.HoughLinesP for a batch uint8[N,H,W] (numpy or ROCm tensor): per image int32[n,1,4]
+    (x0, y0, x1, y1) in the order cv2 finds the segments, or None."""
+    L = _native.lib()
+    if rho <= 0 or theta <= 0:
+        raise error("HoughLinesP: rho and theta must be greater 0")
+    s = upload(images, 1, batched=True)
+    n = s.batch
+    if n == 0:
+        return []
+    dev = s.t.device
+    ws = workspace(L.ipa_hough_lines_p_workspace_bytes(s.width, s.height, n, float(rho), float(theta), 0))
+    while True:
+        lines = torch.empty((n, max(max_lines, 1), 4), dtype=torch.int32, device=dev)
+        counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        check(L.ipa_hough_lines_p_u8(s.ptr, s.pitch, s.stride, s.width, s.height, n, float(rho), float(theta), int(threshold),
+                                     int(minLineLength), int(maxLineGap), 0, lines.data_ptr(), int(max_lines),
+                                     counts.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()))
+        c = counts.cpu().numpy()
+        if (c < 0).any():
+            raise error("HoughLinesP: internal list capacity exceeded")
+        if c.max(initial=0) > max_lines:
+            max_lines = int(c.max())
+            continue
+        out = []
+        for i in range(n):
+            if c[i] == 0:
+                out.append(None)
+            else:
+                seg = lines[i, : int(c[i])].reshape(-1, 1, 4)
+                out.append(seg.clone() if _is_torch(images) else seg.cpu().numpy())
+        return out
+
+
+def HoughLinesP(image, rho, theta, threshold, lines=None, minLineLength=0, maxLineGap=0):
+    """cv2.HoughLinesP(image, rho, theta, threshold, minLineLength=, maxLineGap=) -> int32[N,1,4] or None
+    (lineDetection.py:12-19, "New Version/comparison.py":14)."""
+    m = image if _is_torch(image) else np.asarray(image)
+    if m.ndim != 2:
+        raise error("HoughLinesP: a single-channel 8-bit image is required")
+    return hough_lines_p_batch(m[None], rho, theta, threshold, minLineLength, maxLineGap)[0]

@@ -277,6 +277,24 @@ int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t mask_stride,
                     int32_t* boxes, int max_boxes, int32_t* counts,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* cv2.HoughLinesP(edges, rho, theta, threshold, minLineLength=, maxLineGap=)
+ * (lineDetection.py:12-19, "New Version/comparison.py":14,
+ * newVersion3/detectHorizontalVerticalLines.py:64): the progressive probabilistic Hough transform.
+ * The visits of the non-zero pixels are sequential by definition (pseudo-random order from
+ * cv::RNG, every visit changes accumulator and mask), so one wave runs one image and a batch
+ * runs as many waves side by side.  For image b, lines + b*max_lines*4 receives up to max_lines
+ * segments (x0, y0, x1, y1) in the order cv2 finds them; counts[b] receives their number (may
+ * exceed max_lines: retry with more room) or -1 when the image has more non-zero pixels than
+ * `max_points` (0 = width*height, always enough).  The accumulator has numangle x numrho cells
+ * (ipa_hough_lines_p_dims: numrho = round((2 (width + height) + 1) / rho)) per image in `ws`. */
+int ipa_hough_lines_p_dims(int width, int height, double rho, double theta, int* numangle, int* numrho);
+size_t ipa_hough_lines_p_workspace_bytes(int width, int height, int batch, double rho, double theta, int max_points);
+int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                         int width, int height, int batch, double rho, double theta,
+                         int threshold, int min_line_length, int max_line_gap, int max_points,
+                         int32_t* lines, int max_lines, int32_t* counts,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* ---- fused front-end ---------------------------------------------------- */
 
 /* One pass of the whole raster front-end over a batch of BGR images: the

@@ -786,6 +786,131 @@ FR_API int fr_external_boxes(const u8* src, size_t sp, int w, int h, int* boxes,
 
 
 /* ------------------------------------------------------------------ */
+/* cv2.HoughLinesP(edges, rho, theta, threshold, minLineLength=, maxLineGap=) --
+ * lineDetection.py:12-19, "New Version/comparison.py":14, detectHorizontalVerticalLines.py:64
+ * and three more scripts.  Restatement of OpenCV 4.x's progressive probabilistic Hough
+ * transform (cv::HoughLinesProbabilistic, hough.cpp): the non-zero pixels are visited in a
+ * pseudo-random order drawn from cv::RNG(0xffffffffffffffff) (multiply-with-carry,
+ * coefficient 4164903690); every visited pixel that still belongs to no line votes for all
+ * angles; when a bin reaches the threshold the line is walked in both directions in 16.16
+ * fixed point, gaps of up to maxLineGap allowed; the pixels of the walked segment leave the
+ * mask and, if the segment is long enough, take their votes back.
+ * lines: int32[cap][4] = (x0, y0, x1, y1); returns the number of segments found. */
+static unsigned frp_rng_next(unsigned long long* st)
+{
+    *st = (unsigned long long)(unsigned)(*st) * 4164903690ULL + (unsigned)(*st >> 32);
+    return (unsigned)(*st);
+}
+
+FR_API void fr_hough_p_dims(int w, int h, double rho, double theta, int* numangle, int* numrho)
+{
+    float frho = (float)rho, ftheta = (float)theta;
+    int na = (int)floor((M_PI - 0.0) / ftheta) + 1;
+    if (na > 1 && fabs(M_PI - (na - 1) * ftheta) < ftheta / 2) --na;
+    *numangle = na;
+    *numrho = (int)lrintf(((w + h) * 2 + 1) / frho);
+}
+
+FR_API int fr_hough_lines_p(const u8* src, size_t sp, int w, int h, double rho_, double theta_, int threshold,
+                            int line_length, int line_gap, int* lines, int cap)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const float rho = (float)rho_, theta = (float)theta_;
+    const float irho = 1 / rho;
+    int numangle, numrho;
+    fr_hough_p_dims(w, h, rho_, theta_, &numangle, &numrho);
+    int* accum = (int*)calloc((size_t)numangle * numrho, sizeof(int));
+    u8* mask = (u8*)malloc((size_t)w * h);
+    float* ttab = (float*)malloc(sizeof(float) * 2 * (size_t)numangle);
+    int* nz = (int*)malloc(sizeof(int) * 2 * (size_t)w * h);
+    if (!accum || !mask || !ttab || !nz) { free(accum); free(mask); free(ttab); free(nz); return -1; }
+    for (int n = 0; n < numangle; n++) {
+        ttab[2 * n] = (float)(cos((double)n * theta) * irho);
+        ttab[2 * n + 1] = (float)(sin((double)n * theta) * irho);
+    }
+    int count = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int on = src[(size_t)y * sp + x] != 0;
+            mask[(size_t)y * w + x] = (u8)on;
+            if (on) { nz[2 * count] = x; nz[2 * count + 1] = y; count++; }
+        }
+    unsigned long long rng = 0xffffffffffffffffULL;
+    int nlines = 0;
+    const int shift = 16;
+    for (; count > 0; count--) {
+        const int idx = (int)(frp_rng_next(&rng) % (unsigned)count);
+        const int j = nz[2 * idx], i = nz[2 * idx + 1];
+        nz[2 * idx] = nz[2 * (count - 1)];
+        nz[2 * idx + 1] = nz[2 * (count - 1) + 1];
+        if (!mask[(size_t)i * w + j]) continue;
+        int max_val = threshold - 1, max_n = 0;
+        for (int n = 0; n < numangle; n++) {
+            const float fr = (float)j * ttab[2 * n] + (float)i * ttab[2 * n + 1];
+            const int r = (int)lrintf(fr) + (numrho - 1) / 2;
+            const int val = ++accum[(size_t)n * numrho + r];
+            if (max_val < val) { max_val = val; max_n = n; }
+        }
+        if (max_val < threshold) continue;
+        const float a = -ttab[2 * max_n + 1], b = ttab[2 * max_n];
+        int x0 = j, y0 = i, dx0, dy0, xflag;
+        if (fabsf(a) > fabsf(b)) {
+            xflag = 1;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = (int)lrintf(b * (float)(1 << shift) / fabsf(a));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = 0;
+            dy0 = b > 0 ? 1 : -1;
+            dx0 = (int)lrintf(a * (float)(1 << shift) / fabsf(b));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        int ex[2] = {0, 0}, ey[2] = {0, 0};
+        for (int k = 0; k < 2; k++) {
+            int gap = 0, x = x0, y = y0, dx = dx0, dy = dy0;
+            if (k > 0) dx = -dx, dy = -dy;
+            for (;; x += dx, y += dy) {
+                const int j1 = xflag ? x : x >> shift, i1 = xflag ? y >> shift : y;
+                if (j1 < 0 || j1 >= w || i1 < 0 || i1 >= h) break;
+                if (mask[(size_t)i1 * w + j1]) {
+                    gap = 0;
+                    ey[k] = i1;
+                    ex[k] = j1;
+                } else if (++gap > line_gap)
+                    break;
+            }
+        }
+        const int good = abs(ex[1] - ex[0]) >= line_length || abs(ey[1] - ey[0]) >= line_length;
+        for (int k = 0; k < 2; k++) {
+            int x = x0, y = y0, dx = dx0, dy = dy0;
+            if (k > 0) dx = -dx, dy = -dy;
+            for (;; x += dx, y += dy) {
+                const int j1 = xflag ? x : x >> shift, i1 = xflag ? y >> shift : y;
+                u8* m = mask + (size_t)i1 * w + j1;
+                if (*m) {
+                    if (good)
+                        for (int n = 0; n < numangle; n++) {
+                            const float fr = (float)j1 * ttab[2 * n] + (float)i1 * ttab[2 * n + 1];
+                            accum[(size_t)n * numrho + (int)lrintf(fr) + (numrho - 1) / 2]--;
+                        }
+                    *m = 0;
+                }
+                if (i1 == ey[k] && j1 == ex[k]) break;
+            }
+        }
+        if (good) {
+            if (nlines < cap) {
+                lines[4 * nlines] = ex[0]; lines[4 * nlines + 1] = ey[0];
+                lines[4 * nlines + 2] = ex[1]; lines[4 * nlines + 3] = ey[1];
+            }
+            nlines++;
+        }
+    }
+    free(accum); free(mask); free(ttab); free(nz);
+    return nlines;
+}
+
+/* ------------------------------------------------------------------ */
 /* The caller compositions of the reference, restated for the CPU baseline:
  * load_image_from_file / threshold_image / extract_lines
  * (umlClassdiagram.py:12-30 and siblings) followed by the line-detection

@@ -215,6 +215,23 @@ def external_boxes(mask, cap=1 << 20):
     return out[: min(n, cap)].copy()
 
 
+def hough_lines_p(img, rho, theta, threshold, min_line_length=0, max_line_gap=0, cap=1 << 16):
+    """cv2.HoughLinesP(img, rho, theta, threshold, minLineLength=, maxLineGap=): int32[N,1,4] or None."""
+    m = _c(np.asarray(img, dtype=np.uint8))
+    h, w = m.shape
+    out = np.zeros((max(cap, 1), 4), np.int32)
+    f = lib().fr_hough_lines_p
+    f.restype = C.c_int
+    n = f(_p(m), C.c_size_t(m.strides[0] if h else 0), C.c_int(w), C.c_int(h), C.c_double(rho), C.c_double(theta),
+          C.c_int(int(threshold)), C.c_int(int(min_line_length)), C.c_int(int(max_line_gap)),
+          out.ctypes.data_as(C.c_void_p), C.c_int(cap))
+    if n < 0:
+        raise MemoryError("fr_hough_lines_p")
+    if n > cap:
+        return hough_lines_p(img, rho, theta, threshold, min_line_length, max_line_gap, cap=n)
+    return out[:n].reshape(n, 1, 4).copy() if n else None
+
+
 def front_end(bgr, t=128, line_len=15, iterations=2, c_lo=50.0, c_hi=150.0, with_hough=True):
     """gray, thresh, vlines, hlines, edges, accum for one BGR image (CPU baseline unit of work)."""
     bgr = _c(bgr)

@@ -618,3 +618,68 @@ def test_segments_large_image_property():
     keys = [(y, x) for x, y, _, _ in got]
     assert keys == sorted(keys, reverse=True)
     _seg_same(got, m)
+
+
+# ------------------------------------------------------------------ HoughLinesP
+# Expected values: the oracle's restatement of cv::HoughLinesProbabilistic ("restatement", parity
+# unpinned: no cv2-written line list exists).  Order and end points must agree exactly.
+def _hp_same(img, rho, theta, thr, ml, mg):
+    got = cv2.HoughLinesP(img, rho, theta, thr, minLineLength=ml, maxLineGap=mg)
+    want = fr.hough_lines_p(img, rho, theta, thr, ml, mg)
+    assert (got is None) == (want is None)
+    if want is not None:
+        assert got.shape == want.shape and got.dtype == np.int32
+        assert np.array_equal(got, want)
+
+
+def test_hough_lines_p_known_shapes():
+    m = np.zeros((40, 60), np.uint8)
+    m[10, 5:50] = 255
+    m[5:35, 20] = 255
+    _hp_same(m, 1, np.pi / 180, 15, 10, 2)
+    assert cv2.HoughLinesP(np.zeros((20, 20), np.uint8), 1, np.pi / 180, 5, minLineLength=3, maxLineGap=1) is None
+    m = np.zeros((30, 80), np.uint8)
+    m[12, 4:30] = 255
+    m[12, 33:70] = 255
+    for gap in (0, 2, 3, 10):
+        for ml in (0, 5, 30, 100):
+            _hp_same(m, 1, np.pi / 180, 10, ml, gap)
+    m = np.zeros((64, 64), np.uint8)
+    for k in range(8, 56):
+        m[k, k] = 255
+        m[k, 63 - k] = 255
+    _hp_same(m, 1, np.pi / 180, 20, 10, 0)
+    _hp_same(m, 2, np.pi / 90, 10, 5, 1)
+    _hp_same(np.full((9, 13), 255, np.uint8), 1, np.pi / 180, 3, 2, 0)
+    _hp_same(np.ones((1, 1), np.uint8), 1, np.pi / 180, 1, 0, 0)
+
+
+def test_hough_lines_p_reference_images(cd_bgr, login_bgr):
+    # lineDetection.py:5-19 on the image it loads, and the class diagram
+    for bgr in (login_bgr, cd_bgr):
+        e = fr.canny(fr.bgr2gray(bgr), 50, 150)
+        for thr, ml, mg in ((100, 100, 10), (50, 50, 10), (30, 5, 0), (80, 30, 5)):
+            _hp_same(e, 1, np.pi / 180, thr, ml, mg)
+
+
+def test_hough_lines_p_random_and_batch():
+    rng = np.random.default_rng(17)
+    for h, w, p in ((33, 47, 0.2), (64, 64, 0.5), (70, 129, 0.05)):
+        m = ((rng.random((h, w)) < p) * 255).astype(np.uint8)
+        _hp_same(m, 1, np.pi / 180, 8, 4, 1)
+    imgs = np.stack([fr.canny(fr.bgr2gray(uml_like(500 + i, 200, 320)), 50, 150) for i in range(6)])
+    imgs[4] = 0
+    got = cv2.hough_lines_p_batch(imgs, 1, np.pi / 180, 40, minLineLength=30, maxLineGap=5, max_lines=2)  # forces the retry
+    for i in range(6):
+        want = fr.hough_lines_p(imgs[i], 1, np.pi / 180, 40, 30, 5)
+        assert (got[i] is None) == (want is None)
+        if want is not None:
+            assert np.array_equal(got[i], want)
+    t = torch.from_numpy(imgs[0]).cuda()
+    r = cv2.HoughLinesP(t, 1, np.pi / 180, 40, minLineLength=30, maxLineGap=5)
+    assert isinstance(r, torch.Tensor) and np.array_equal(r.cpu().numpy(), fr.hough_lines_p(imgs[0], 1, np.pi / 180, 40, 30, 5))
+
+
+def test_hough_lines_p_1080p():
+    e = fr.canny(fr.bgr2gray(uml_like(1000, 1080, 1920)), 50, 150)
+    _hp_same(e, 1, np.pi / 180, 100, 100, 10)

@@ -255,3 +255,51 @@ def test_external_boxes_on_line_masks(cd_bgr):
         a = fr.external_boxes(lines)
         assert len(a) >= 2 and np.array_equal(a, nr.external_boxes(lines))
     assert np.array_equal(fr.external_boxes(t), nr.external_boxes(t))
+
+
+# ------------------------------------------------------------------ HoughLinesP (restatement; parity unpinned)
+def _segs(l):
+    return [] if l is None else sorted(tuple(int(v) for v in s) for s in l.reshape(-1, 4))
+
+
+def _norm(seg):
+    x0, y0, x1, y1 = seg
+    return (x0, y0, x1, y1) if (x0, y0) <= (x1, y1) else (x1, y1, x0, y0)
+
+
+def test_hough_lines_p_known_answers():
+    # lineDetection.py:12: HoughLinesP(edges, 1, pi/180, threshold, minLineLength=, maxLineGap=)
+    m = np.zeros((40, 60), np.uint8)
+    m[10, 5:50] = 255
+    m[5:35, 20] = 255
+    got = {_norm(s) for s in _segs(fr.hough_lines_p(m, 1, np.pi / 180, 15, 10, 2))}
+    assert got == {(5, 10, 49, 10), (20, 5, 20, 34)}
+    assert fr.hough_lines_p(np.zeros((20, 20), np.uint8), 1, np.pi / 180, 5, 3, 1) is None
+    # a gap of 3 pixels: bridged with maxLineGap >= 3, two segments below
+    m = np.zeros((30, 80), np.uint8)
+    m[12, 4:30] = 255
+    m[12, 33:70] = 255
+    one = {_norm(s) for s in _segs(fr.hough_lines_p(m, 1, np.pi / 180, 10, 5, 3))}
+    two = {_norm(s) for s in _segs(fr.hough_lines_p(m, 1, np.pi / 180, 10, 5, 2))}
+    assert one == {(4, 12, 69, 12)}
+    assert two == {(4, 12, 29, 12), (33, 12, 69, 12)}
+    # minLineLength drops the short bar, and its pixels are used up all the same
+    assert {_norm(s) for s in _segs(fr.hough_lines_p(m, 1, np.pi / 180, 10, 30, 2))} == {(33, 12, 69, 12)}
+    # a 45-degree diagonal
+    m = np.zeros((64, 64), np.uint8)
+    for k in range(8, 56):
+        m[k, k] = 255
+    assert {_norm(s) for s in _segs(fr.hough_lines_p(m, 1, np.pi / 180, 20, 10, 0))} == {(8, 8, 55, 55)}
+
+
+def test_hough_lines_p_uses_every_pixel_once(cd_bgr):
+    # every segment lies inside the image, is at least minLineLength long on one axis, and a second
+    # run gives the same list (the pseudo-random visiting order is fixed)
+    e = fr.canny(fr.bgr2gray(cd_bgr), 50, 150)
+    a = fr.hough_lines_p(e, 1, np.pi / 180, 50, 50, 10)
+    b = fr.hough_lines_p(e, 1, np.pi / 180, 50, 50, 10)
+    assert a is not None and np.array_equal(a, b)
+    h, w = e.shape
+    s = a.reshape(-1, 4)
+    assert (s[:, [0, 2]] >= 0).all() and (s[:, [0, 2]] < w).all() and (s[:, [1, 3]] >= 0).all() and (s[:, [1, 3]] < h).all()
+    assert (np.maximum(abs(s[:, 2] - s[:, 0]), abs(s[:, 3] - s[:, 1])) >= 50).all()
