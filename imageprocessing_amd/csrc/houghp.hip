@@ -39,6 +39,7 @@ struct HpArgs {
     int32_t* lines;  // [batch][max_lines][4]
     int max_lines;
     int32_t* counts;  // [batch] segments found (may exceed max_lines), -1: list capacity exceeded
+    long long* stats;  // debug: per-phase wall-clock ticks of image 0 (or NULL)
 };
 
 // one wave per row
@@ -119,6 +120,16 @@ __device__ __forceinline__ int hp_rho(int x, int y, float c, float s)
 }
 
 // One wave per image.  Everything that steers control flow is wave-uniform.
+//
+// The visits are taken 64 at a time where that provably changes nothing:
+//  * the order of the draws does not depend on the image (the list shrinks by one entry per draw
+//    whatever the pixel turns out to be), so the 64 list operations of a batch are done by the 64
+//    lanes at once unless two of them touch the same list position (then the batch runs one draw
+//    at a time);
+//  * pixels whose mask bit is already clear are skipped by all lanes at once;
+//  * votes that trigger no segment commute, so the live pixels of a batch vote side by side
+//    (lane = pixel); if any bin they touched ends at or above the threshold the votes are taken
+//    back and the batch is replayed one visit at a time (lanes = angles / steps of the line walk).
 __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -134,27 +145,28 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
     const int w = A.w, h = A.h, numangle = A.numangle, numrho = A.numrho, half = (numrho - 1) / 2;
     const int shift = 16;
     auto mask_at = [&](int i1, int j1) -> u32 { return (ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) >> (j1 & 31)) & 1u; };
-    unsigned long long rng = 0xffffffffffffffffULL;
     int nlines = 0;
-    for (; count > 0; count--) {
-        rng = (unsigned long long)(u32)rng * 4164903690ULL + (u32)(rng >> 32);
-        const u32 idx = (u32)rng % (u32)count;
-        // draw without replacement: the last entry takes the drawn entry's place
-        const u32 p = ld_l2(&nz[idx]);
-        const u32 last = ld_l2(&nz[count - 1]);
-        if (lane == 0) st_l2(&nz[idx], last);
-        const int i = (int)(p >> 16), j = (int)(p & 0xffffu);
-        if (!mask_at(i, j)) continue;  // already part of a segment
+
+    // one visit of pixel (row i, column j), exactly as cv2 orders its steps
+    auto visit = [&](const int i, const int j) {
+        if (!mask_at(i, j)) return;  // already part of a segment
 
         // vote; the winner is the first angle whose bin holds the largest count
         int best_val = -1, best_n = 0;
-        for (int n = lane; n < numangle; n += 64) {
-            const int r = hp_rho(j, i, T.c[n], T.s[n]) + half;
-            const int val = atomicAdd(&acc[(size_t)n * numrho + r], 1) + 1;
-            if (val > best_val) {
-                best_val = val;
-                best_n = n;
+        for (int n0 = lane; n0 < numangle; n0 += 256) {  // four atomics in flight per lane
+            int val[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int n = n0 + 64 * q;
+                val[q] = -1;
+                if (n < numangle) val[q] = atomicAdd(&acc[(size_t)n * numrho + hp_rho(j, i, T.c[n], T.s[n]) + half], 1) + 1;
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (val[q] > best_val) {
+                    best_val = val[q];
+                    best_n = n0 + 64 * q;
+                }
         }
         unsigned long long key = ((unsigned long long)(u32)(best_val + 1) << 32) | (u32)(0x7fffffff - best_n);
 #pragma unroll
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
             key = other > key ? other : key;
         }
         const int max_val = (int)(key >> 32) - 1, max_n = 0x7fffffff - (int)(u32)key;
-        if (max_val < A.threshold) continue;
+        if (max_val < A.threshold) return;
 
         // direction of the line and its 16.16 fixed-point step
         const float a = -T.s[max_n], bb = T.c[max_n];
@@ -254,7 +266,97 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
             }
             nlines++;
         }
+    };
+
+    const unsigned long long RNG_COEFF = 4164903690ULL;
+    unsigned long long rng = 0xffffffffffffffffULL;
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tk = wall_clock64();
+    auto lap = [&](int k) { const long long now = wall_clock64(); st[k] += now - tk; tk = now; };
+    while (count > 0) {
+        st[5]++;
+        const int K = count < 64 ? count : 64;
+        // the next K draws: lane t keeps the t-th
+        unsigned long long x = rng;
+        u32 mine = 0;
+        for (int t = 0; t < K; t++) {
+            x = (unsigned long long)(u32)x * RNG_COEFF + (u32)(x >> 32);
+            if (lane == t) mine = (u32)x;
+        }
+        const bool act = lane < K;
+        const u32 idx = act ? mine % (u32)(count - lane) : 0xffffffffu;
+        // do two of the K list operations touch one position?  (a drawn position drawn again, or a
+        // drawn position that is the last entry of a later draw)
+        bool coll = false;
+        for (int u = 0; u < K; u++) {
+            const u32 iu = (u32)__shfl((int)idx, u);
+            coll |= act && ((lane > u && idx == iu) || (lane < u && idx == (u32)(count - 1 - u)));
+        }
+        lap(0);
+        if (__any(coll)) {
+            st[6]++;
+            for (int t = 0; t < K; t++, count--) {
+                rng = (unsigned long long)(u32)rng * RNG_COEFF + (u32)(rng >> 32);
+                const u32 id1 = (u32)rng % (u32)count;
+                const u32 p1 = ld_l2(&nz[id1]);
+                const u32 last = ld_l2(&nz[count - 1]);
+                if (lane == 0) st_l2(&nz[id1], last);
+                __threadfence();
+                visit((int)(p1 >> 16), (int)(p1 & 0xffffu));
+            }
+            lap(1);
+            continue;
+        }
+        // draw without replacement: the last entry takes the drawn entry's place
+        u32 p = 0;
+        if (act) {
+            p = ld_l2(&nz[idx]);
+            const u32 last = ld_l2(&nz[count - 1 - lane]);
+            st_l2(&nz[idx], last);
+        }
+        __threadfence();
+        const int pi = (int)(p >> 16), pj = (int)(p & 0xffffu);
+        const bool live = act && mask_at(pi, pj);
+        const unsigned long long LV = __ballot(live);
+        lap(2);
+        if (LV) {
+            int mx = 0;
+            if (live) {
+                int n = 0;
+                for (; n + 12 <= numangle; n += 12) {  // twelve atomics in flight per lane
+                    int v[12];
+#pragma unroll
+                    for (int q = 0; q < 12; q++)
+                        v[q] = atomicAdd(&acc[(size_t)(n + q) * numrho + hp_rho(pj, pi, T.c[n + q], T.s[n + q]) + half], 1);
+#pragma unroll
+                    for (int q = 0; q < 12; q++) mx = v[q] >= mx ? v[q] + 1 : mx;
+                }
+                for (; n < numangle; n++) {
+                    const int v = atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], 1) + 1;
+                    mx = v > mx ? v : mx;
+                }
+            }
+            const bool replay = __any(live && mx >= A.threshold);
+            lap(3);
+            if (replay) {
+                st[7]++;
+                if (live)
+                    for (int n = 0; n < numangle; n++)
+                        atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], -1);
+                __threadfence();
+                for (int t = 0; t < K; t++) {
+                    if (!((LV >> t) & 1ULL)) continue;  // mask bits are only ever cleared
+                    const u32 pt = (u32)__shfl((int)p, t);
+                    visit((int)(pt >> 16), (int)(pt & 0xffffu));
+                }
+                lap(4);
+            }
+        }
+        count -= K;
+        rng = x;
     }
+    if (A.stats && b == 0 && lane == 0)
+        for (int k = 0; k < 8; k++) A.stats[k] = st[k];
     if (lane == 0) A.counts[b] = nlines;
 }
 
@@ -357,6 +459,15 @@ IPA_EXPORT int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t
     A.w = width; A.h = height; A.numangle = na; A.numrho = nr;
     A.threshold = threshold; A.line_length = min_line_length; A.line_gap = max_line_gap;
     A.lines = lines; A.max_lines = max_lines; A.counts = counts;
+    A.stats = nullptr;
+    if (getenv("IPA_HP_STATS")) {
+        static long long* dbg = nullptr;
+        if (!dbg) IPA_HIP(hipHostMalloc((void**)&dbg, 64, 0));
+        A.stats = dbg;
+        static long long* prev = nullptr;
+        if (prev) fprintf(stderr, "hp stats (10 ns ticks): rng+coll %lld seqfallback %lld list+mask %lld specvote %lld replay %lld | batches %lld collisions %lld replays %lld\n", prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], prev[7]);
+        prev = dbg;
+    }
     HpTrig T;
     {
         // cv::HoughLinesProbabilistic: trigtab[n] = (float)(cos((double)n * theta) / rho) with float rho, theta

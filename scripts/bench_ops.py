@@ -76,6 +76,9 @@ def main():
         return lambda: chk(L.ipa_segments_u8(src.ptr, src.pitch, src.stride, w, h, n, 0, boxes.data_ptr(), 4096, nbox.data_ptr(),
                                              ws.data_ptr(), ws.numel(), st))
 
+    hp_ws = workspace(L.ipa_hough_lines_p_workspace_bytes(w, h, n, 1.0, np.pi / 180, w * h // 4))
+    hp_lines = torch.empty((n, 4096, 4), dtype=torch.int32, device="cuda")
+
     ops = [
         ("cvtColor BGR2GRAY", 4 * px, lambda: chk(L.ipa_bgr2gray_u8(bgr.ptr, bgr.pitch, bgr.stride, gray.ptr, gray.pitch, gray.stride, w, h, n, st))),
         ("threshold BINARY_INV", 2 * px, lambda: chk(L.ipa_threshold_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 128.0, 255.0, 1, st))),
@@ -94,6 +97,7 @@ def main():
         ("open 15x1 it=2 (gray)", 2 * px, morph(2, 15, 1, 2, 0, gray)),
         ("Canny 50/150", 2 * px, lambda: chk(L.ipa_canny_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 50.0, 150.0, ws.data_ptr(), ws.numel(), st))),
         ("HoughLines accumulator", px + acc_bytes, lambda: chk(L.ipa_hough_accum_u8(edges.ptr, edges.pitch, edges.stride, w, h, n, 1.0, np.pi / 180, acc.data_ptr(), acc.stride(0), seg.data_ptr(), w * h // 4, cnt.data_ptr(), ws.data_ptr(), ws.numel(), st))),
+        ("HoughLinesP 100/100/10", px, lambda: chk(L.ipa_hough_lines_p_u8(edges.ptr, edges.pitch, edges.stride, w, h, n, 1.0, np.pi / 180, 100, 100, 10, w * h // 4, hp_lines.data_ptr(), 4096, nbox.data_ptr(), hp_ws.data_ptr(), hp_ws.numel(), st))),
         ("get_segments (hlines mask)", px, segments(hl)),
         ("get_segments (thresh mask)", px, segments(thr)),
         ("erase rects (4 per image)", 0.0, lambda: chk(L.ipa_fill_rects_c3_u8(bgr.ptr, bgr.pitch, bgr.stride, w, h, n, rects.data_ptr(), rects.shape[0], 255, 255, 255, st))),
