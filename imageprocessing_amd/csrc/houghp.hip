@@ -198,33 +198,51 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
             i1 = xflag ? y >> shift : y;
         };
 
-        // first walk: how far the segment reaches in each direction (step index of its last pixel)
+        // first walk: how far the segment reaches in each direction (step index of its last pixel);
+        // WCH chunks of 64 steps per round trip to the mask
+        constexpr int WCH = 4;
         int last_step[2] = {0, 0};
         for (int k = 0; k < 2; k++) {
             int gap = 0;
             bool stop = false;
-            for (int base = 0; !stop; base += 64) {
-                int i1, j1;
-                pos_at(k, base + lane, i1, j1);
-                const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
-                const bool on = inb && mask_at(i1, j1);
-                const unsigned long long M = __ballot(on), O = __ballot(!inb);
-                if (O == 0 && M == ~0ULL) {
-                    gap = 0;
-                    last_step[k] = base + 63;
-                    continue;
+            for (int base = 0; !stop; base += 64 * WCH) {
+                unsigned long long M[WCH], O[WCH];
+                u32 word[WCH];
+                int bitpos[WCH];
+                bool inb[WCH];
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    int i1, j1;
+                    pos_at(k, base + 64 * q + lane, i1, j1);
+                    inb[q] = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                    bitpos[q] = j1 & 31;
+                    word[q] = inb[q] ? ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) : 0u;
                 }
-                for (int t = 0; t < 64; t++) {
-                    if ((O >> t) & 1ULL) {
-                        stop = true;
-                        break;
-                    }
-                    if ((M >> t) & 1ULL) {
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    M[q] = __ballot(inb[q] && ((word[q] >> bitpos[q]) & 1u));
+                    O[q] = __ballot(!inb[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    if (stop) break;
+                    if (O[q] == 0 && M[q] == ~0ULL) {
                         gap = 0;
-                        last_step[k] = base + t;
-                    } else if (++gap > A.line_gap) {
-                        stop = true;
-                        break;
+                        last_step[k] = base + 64 * q + 63;
+                        continue;
+                    }
+                    for (int t = 0; t < 64; t++) {
+                        if ((O[q] >> t) & 1ULL) {
+                            stop = true;
+                            break;
+                        }
+                        if ((M[q] >> t) & 1ULL) {
+                            gap = 0;
+                            last_step[k] = base + 64 * q + t;
+                        } else if (++gap > A.line_gap) {
+                            stop = true;
+                            break;
+                        }
                     }
                 }
             }
@@ -237,26 +255,45 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
         // second walk: the segment's pixels leave the mask and, for a kept segment, take their votes
         // back.  Step 0 (the drawn pixel itself) belongs to both directions; it is handled once.
         for (int k = 0; k < 2; k++) {
-            for (int base = k; base <= last_step[k]; base += 64) {
-                int i1, j1;
-                const int t = base + lane;
-                pos_at(k, t, i1, j1);
-                const bool on = t <= last_step[k] && mask_at(i1, j1);
-                unsigned long long M = __ballot(on);
-                if (on) atomicAnd(&bits[(size_t)i1 * A.bpw + (j1 >> 5)], ~(1u << (j1 & 31)));
+            for (int base = k; base <= last_step[k]; base += 64 * WCH) {
+                unsigned long long M[WCH];
+                u32 word[WCH];
+                u32* wp[WCH];
+                int bitpos[WCH];
+                bool in_seg[WCH];
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    int i1, j1;
+                    const int t = base + 64 * q + lane;
+                    pos_at(k, t, i1, j1);
+                    in_seg[q] = t <= last_step[k];
+                    bitpos[q] = j1 & 31;
+                    wp[q] = &bits[(size_t)i1 * A.bpw + (j1 >> 5)];
+                    word[q] = in_seg[q] ? ld_l2(wp[q]) : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    const bool on = in_seg[q] && ((word[q] >> bitpos[q]) & 1u);
+                    M[q] = __ballot(on);
+                    if (on) atomicAnd(wp[q], ~(1u << bitpos[q]));
+                }
                 if (good) {
-                    while (M) {
-                        const int tt = base + (__ffsll((long long)M) - 1);
-                        M &= M - 1;
-                        int iu, ju;
-                        pos_at(k, tt, iu, ju);
-                        for (int n = lane; n < numangle; n += 64)
-                            atomicAdd(&acc[(size_t)n * numrho + hp_rho(ju, iu, T.c[n], T.s[n]) + half], -1);
+#pragma unroll
+                    for (int q = 0; q < WCH; q++) {
+                        unsigned long long m = M[q];
+                        while (m) {
+                            const int tt = base + 64 * q + (__ffsll((long long)m) - 1);
+                            m &= m - 1;
+                            int iu, ju;
+                            pos_at(k, tt, iu, ju);
+                            for (int n = lane; n < numangle; n += 64)
+                                atomicAdd(&acc[(size_t)n * numrho + hp_rho(ju, iu, T.c[n], T.s[n]) + half], -1);
+                        }
                     }
                 }
             }
         }
-        __threadfence();  // the next visit reads what this one changed
+        __threadfence_block();  // the next visit reads what this one changed
         if (good) {
             if (lane == 0 && nlines < A.max_lines) {
                 lines[4 * nlines + 0] = ex[0];
@@ -275,7 +312,7 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
     auto lap = [&](int k) { const long long now = wall_clock64(); st[k] += now - tk; tk = now; };
     while (count > 0) {
         st[5]++;
-        const int K = count < 64 ? count : 64;
+        int K = count < 64 ? count : 64;
         // the next K draws: lane t keeps the t-th
         unsigned long long x = rng;
         u32 mine = 0;
@@ -283,30 +320,26 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
             x = (unsigned long long)(u32)x * RNG_COEFF + (u32)(x >> 32);
             if (lane == t) mine = (u32)x;
         }
-        const bool act = lane < K;
-        const u32 idx = act ? mine % (u32)(count - lane) : 0xffffffffu;
-        // do two of the K list operations touch one position?  (a drawn position drawn again, or a
-        // drawn position that is the last entry of a later draw)
-        bool coll = false;
-        for (int u = 0; u < K; u++) {
-            const u32 iu = (u32)__shfl((int)idx, u);
-            coll |= act && ((lane > u && idx == iu) || (lane < u && idx == (u32)(count - 1 - u)));
+        const u32 idx = lane < K ? mine % (u32)(count - lane) : 0xffffffffu;
+        // Two of the K list operations may touch one position (a drawn position drawn again, or a
+        // drawn position that is the last entry of a later draw): the batch ends before the later of
+        // the two.  Draw 0 never is the later one.
+        u32 later = 64;  // per lane: the smallest later partner of a clash this lane is the earlier part of
+        for (int u = 1; u < K; u++) {
+            const u32 iu = (u32)__builtin_amdgcn_readlane((int)idx, u);
+            if (lane < u && (idx == iu || idx == (u32)(count - 1 - u))) later = min(later, (u32)u);
         }
-        lap(0);
-        if (__any(coll)) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) later = min(later, (u32)__shfl_xor((int)later, o));
+        if ((int)later < K) {
+            K = (int)later;
             st[6]++;
-            for (int t = 0; t < K; t++, count--) {
-                rng = (unsigned long long)(u32)rng * RNG_COEFF + (u32)(rng >> 32);
-                const u32 id1 = (u32)rng % (u32)count;
-                const u32 p1 = ld_l2(&nz[id1]);
-                const u32 last = ld_l2(&nz[count - 1]);
-                if (lane == 0) st_l2(&nz[id1], last);
-                __threadfence();
-                visit((int)(p1 >> 16), (int)(p1 & 0xffffu));
-            }
-            lap(1);
-            continue;
+            // the generator restarts behind draw K - 1
+            x = rng;
+            for (int t = 0; t < K; t++) x = (unsigned long long)(u32)x * RNG_COEFF + (u32)(x >> 32);
         }
+        const bool act = lane < K;
+        lap(0);
         // draw without replacement: the last entry takes the drawn entry's place
         u32 p = 0;
         if (act) {
@@ -314,43 +347,50 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
             const u32 last = ld_l2(&nz[count - 1 - lane]);
             st_l2(&nz[idx], last);
         }
-        __threadfence();
+        __threadfence_block();
         const int pi = (int)(p >> 16), pj = (int)(p & 0xffffu);
-        const bool live = act && mask_at(pi, pj);
-        const unsigned long long LV = __ballot(live);
         lap(2);
-        if (LV) {
+        // Votes that trigger no segment commute: the live pixels from `start` on vote side by side
+        // (lane = pixel).  A pixel none of whose bins ends at or above the threshold cannot have
+        // triggered a segment in cv2's order either; the first pixel that might is visited on its own
+        // (after the votes from it on have been taken back), and the rest of the batch starts over.
+        auto vote_all = [&](bool on, int delta) {
+            if (on)
+                for (int n = 0; n < numangle; n++)
+                    atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], delta);
+        };
+        for (int start = 0; start < K;) {
+            const bool live = act && lane >= start && mask_at(pi, pj);
+            if (!__any(live)) break;
+            vote_all(live, 1);
+            __threadfence_block();
             int mx = 0;
             if (live) {
                 int n = 0;
-                for (; n + 12 <= numangle; n += 12) {  // twelve atomics in flight per lane
-                    int v[12];
+                for (; n + 30 <= numangle; n += 30) {  // thirty loads in flight per lane
+                    int v[30];
 #pragma unroll
-                    for (int q = 0; q < 12; q++)
-                        v[q] = atomicAdd(&acc[(size_t)(n + q) * numrho + hp_rho(pj, pi, T.c[n + q], T.s[n + q]) + half], 1);
+                    for (int q = 0; q < 30; q++)
+                        v[q] = (int)ld_l2((const u32*)&acc[(size_t)(n + q) * numrho + hp_rho(pj, pi, T.c[n + q], T.s[n + q]) + half]);
 #pragma unroll
-                    for (int q = 0; q < 12; q++) mx = v[q] >= mx ? v[q] + 1 : mx;
+                    for (int q = 0; q < 30; q++) mx = v[q] > mx ? v[q] : mx;
                 }
                 for (; n < numangle; n++) {
-                    const int v = atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], 1) + 1;
+                    const int v = (int)ld_l2((const u32*)&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half]);
                     mx = v > mx ? v : mx;
                 }
             }
-            const bool replay = __any(live && mx >= A.threshold);
+            const unsigned long long hot = __ballot(live && mx >= A.threshold);
             lap(3);
-            if (replay) {
-                st[7]++;
-                if (live)
-                    for (int n = 0; n < numangle; n++)
-                        atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], -1);
-                __threadfence();
-                for (int t = 0; t < K; t++) {
-                    if (!((LV >> t) & 1ULL)) continue;  // mask bits are only ever cleared
-                    const u32 pt = (u32)__shfl((int)p, t);
-                    visit((int)(pt >> 16), (int)(pt & 0xffffu));
-                }
-                lap(4);
-            }
+            if (!hot) break;
+            st[7]++;
+            const int t1 = __ffsll((long long)hot) - 1;
+            vote_all(live && lane >= t1, -1);
+            __threadfence_block();
+            const u32 pt = (u32)__builtin_amdgcn_readlane((int)p, t1);
+            visit((int)(pt >> 16), (int)(pt & 0xffffu));
+            start = t1 + 1;
+            lap(4);
         }
         count -= K;
         rng = x;
