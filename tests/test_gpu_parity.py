@@ -680,6 +680,17 @@ def test_hough_lines_p_random_and_batch():
     assert isinstance(r, torch.Tensor) and np.array_equal(r.cpu().numpy(), fr.hough_lines_p(imgs[0], 1, np.pi / 180, 40, 30, 5))
 
 
+def test_hough_lines_p_many_images_side_by_side():
+    # one wave per image: 96 different images in one call, each against the oracle
+    imgs = np.stack([fr.canny(fr.bgr2gray(uml_like(700 + i, 120, 200, noise=(3 if i % 4 == 0 else 0))), 50, 150) for i in range(96)])
+    got = cv2.hough_lines_p_batch(imgs, 1, np.pi / 180, 25, minLineLength=20, maxLineGap=3)
+    for i in range(96):
+        want = fr.hough_lines_p(imgs[i], 1, np.pi / 180, 25, 20, 3)
+        assert (got[i] is None) == (want is None), i
+        if want is not None:
+            assert np.array_equal(got[i], want), i
+
+
 def test_hough_lines_p_1080p():
     e = fr.canny(fr.bgr2gray(uml_like(1000, 1080, 1920)), 50, 150)
     _hp_same(e, 1, np.pi / 180, 100, 100, 10)
