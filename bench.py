@@ -262,8 +262,8 @@ def main():
         npix = float(batch) * h * w
         acc_bytes = 4.0 * (fe.na + 2) * (fe.nr + 2)
         stage_names = [L.ipa_profile_stage_name(i).decode() for i in range(nst)]
-        # algorithmic bytes each stage has to move per image (conservative: never more than
-        # the per-op figures of the measurement plan)
+        # algorithmic bytes each stage has to move per image: its compulsory inputs and outputs,
+        # counted once (intermediate re-reads earn nothing)
         alg = {
             "gray_thresh_pack": 5.0 * h * w,          # BGR in (3) + gray out (1) + thresh out (1)
             "open_vertical": 1.125 * h * w,           # 1 bit/px in + 1 B/px out

@@ -1,0 +1,93 @@
+"""Batched form of the service's upload loop (receiveFile.py:22-75 handles the uploaded files one
+by one: imdecode -> gray -> threshold -> extract_lines -> get_segments per file).
+
+Here the files are decoded on a pool of host threads, images of equal size are grouped, every
+group makes one fused device pass (front_end_batch) and one segment pass per line mask, and the
+caller gets the per-image results back in upload order for its downstream (contour / OCR) logic.
+Decoding stays on the host (PIL): palette and gray images are expanded, alpha is dropped, channel
+order is BGR, like cv2.imdecode(..., IMREAD_COLOR) does for 8-bit files; PNG is lossless either
+way, JPEG pixels depend on the decoder library.
+"""
+import io
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass
+class ParsedImage:
+    """What load_image_from_file + threshold_image + extract_lines + get_segments x2
+    (umlClassdiagram.py:12-36) hand to the rest of a parser."""
+    image: np.ndarray                      # uint8[H,W,3] BGR
+    gray: np.ndarray
+    thresh: np.ndarray
+    vlines: np.ndarray
+    hlines: np.ndarray
+    vertical_segments: Optional[List[Tuple[int, int, int, int]]] = None
+    horizontal_segments: Optional[List[Tuple[int, int, int, int]]] = None
+
+
+def decode_bgr(blob) -> Optional[np.ndarray]:
+    """bytes / file-like -> uint8[H,W,3] BGR, or None when the data is no image (cv2.imdecode's None)."""
+    from PIL import Image
+
+    try:
+        data = blob.read() if hasattr(blob, "read") else blob
+        with Image.open(io.BytesIO(bytes(data))) as im:
+            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    except Exception:
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def decode_many(blobs: Iterable, workers: int = 8) -> List[Optional[np.ndarray]]:
+    """Decode on `workers` host threads (PIL releases the GIL while it decompresses); order is kept."""
+    blobs = list(blobs)
+    if not blobs:
+        return []
+    if workers <= 1 or len(blobs) == 1:
+        return [decode_bgr(b) for b in blobs]
+    with ThreadPoolExecutor(max_workers=min(int(workers), len(blobs))) as pool:
+        return list(pool.map(decode_bgr, blobs))
+
+
+def group_by_shape(images: Sequence[Optional[np.ndarray]], max_batch: int = 256) -> Dict[Tuple[int, int], List[List[int]]]:
+    """Indices of the decodable images grouped by (height, width), every group cut into device
+    batches of at most `max_batch` images, upload order kept inside a batch."""
+    if max_batch < 1:
+        raise ValueError("max_batch must be >= 1")
+    by_shape: Dict[Tuple[int, int], List[int]] = {}
+    for i, im in enumerate(images):
+        if im is None:
+            continue
+        if im.ndim != 3 or im.shape[2] != 3 or im.dtype != np.uint8:
+            raise ValueError(f"image {i}: uint8[H,W,3] expected")
+        by_shape.setdefault((int(im.shape[0]), int(im.shape[1])), []).append(i)
+    return {k: [v[o : o + max_batch] for o in range(0, len(v), max_batch)] for k, v in by_shape.items()}
+
+
+def process_images(images: Sequence[Optional[np.ndarray]], thresh_val: int = 128, vert_len: int = 15, horiz_len: int = 15,
+                   iterations: int = 2, segments: bool = True, max_batch: int = 256) -> List[Optional[ParsedImage]]:
+    """The parsers' prefix for many images at once.  ``thresh_val``: 150 class, 128 sequence /
+    activity, 100 state diagrams (umlClassdiagram.py:19, umlSequencediagram.py:22,
+    umlActivitydiagram.py:34, umlStateDiagram.py:19).  Undecodable entries stay None."""
+    from . import pipeline
+
+    out: List[Optional[ParsedImage]] = [None] * len(images)
+    for _, batches in group_by_shape(images, max_batch).items():
+        for idx in batches:
+            stack = np.stack([images[i] for i in idx])
+            res = pipeline.front_end_batch(stack, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
+                                           iterations=iterations, hough=False)
+            vseg = pipeline.segments_batch(res.vlines) if segments else [None] * len(idx)
+            hseg = pipeline.segments_batch(res.hlines) if segments else [None] * len(idx)
+            for k, i in enumerate(idx):
+                out[i] = ParsedImage(images[i], res.gray[k], res.thresh[k], res.vlines[k], res.hlines[k], vseg[k], hseg[k])
+    return out
+
+
+def process_files(blobs: Iterable, workers: int = 8, **kw) -> List[Optional[ParsedImage]]:
+    """decode_many + process_images: the whole upload loop of receiveFile.py:22 up to get_segments."""
+    return process_images(decode_many(blobs, workers), **kw)

@@ -147,3 +147,34 @@ def test_synth_reproducible_and_shaped():
     assert batch.shape == (3, 64, 80, 3) and np.array_equal(batch[1], synth_diagram(6, 64, 80))
     n = synth_diagram(9000, 200, 300, noise=6, gradient=True)
     assert len(np.unique(n)) > 40
+
+
+def test_batching_decode_and_grouping(cd_bgr, login_bgr):
+    # the host half of the batched upload loop (receiveFile.py:22): decode pool + grouping by size
+    import io
+
+    from PIL import Image
+
+    import imageprocessing_amd as ipa
+
+    def png(bgr):
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(buf, format="PNG")
+        return buf.getvalue()
+
+    gray_png = io.BytesIO()
+    Image.fromarray(cd_bgr[:, :, 0]).save(gray_png, format="PNG")
+    rgba = np.dstack([cd_bgr[:, :, ::-1], np.full(cd_bgr.shape[:2], 77, np.uint8)])
+    rgba_png = io.BytesIO()
+    Image.fromarray(rgba, "RGBA").save(rgba_png, format="PNG")
+    blobs = [png(cd_bgr), b"not an image", png(login_bgr), io.BytesIO(png(cd_bgr)), gray_png.getvalue(), rgba_png.getvalue()]
+    imgs = ipa.decode_many(blobs, workers=3)
+    assert imgs[1] is None
+    assert np.array_equal(imgs[0], cd_bgr) and np.array_equal(imgs[2], login_bgr) and np.array_equal(imgs[3], cd_bgr)
+    assert np.array_equal(imgs[4], np.repeat(cd_bgr[:, :, :1], 3, axis=2))     # gray replicated
+    assert np.array_equal(imgs[5], cd_bgr)                                      # alpha dropped
+    assert ipa.decode_many([]) == []
+    groups = ipa.group_by_shape(imgs, max_batch=2)
+    assert groups == {cd_bgr.shape[:2]: [[0, 3], [4, 5]], login_bgr.shape[:2]: [[2]]}
+    with pytest.raises(ValueError):
+        ipa.group_by_shape([cd_bgr[:, :, 0]])

@@ -694,3 +694,31 @@ def test_hough_lines_p_many_images_side_by_side():
 def test_hough_lines_p_1080p():
     e = fr.canny(fr.bgr2gray(uml_like(1000, 1080, 1920)), 50, 150)
     _hp_same(e, 1, np.pi / 180, 100, 100, 10)
+
+
+# ------------------------------------------------------------------ batched upload loop
+def test_process_files_matches_the_per_file_loop(cd_bgr, login_bgr):
+    # receiveFile.py:22 handles uploads one by one; the batched form must hand every parser the
+    # same gray / thresh / line masks / segment lists, in upload order, undecodable files as None
+    import io
+
+    from PIL import Image
+
+    def png(bgr):
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(buf, format="PNG")
+        return buf.getvalue()
+
+    other = uml_like(11, cd_bgr.shape[0], cd_bgr.shape[1])
+    blobs = [png(cd_bgr), b"garbage", png(login_bgr), png(other), png(cd_bgr)]
+    out = cv2.process_files(blobs, workers=2, thresh_val=150, max_batch=2)
+    assert out[1] is None and len(out) == 5
+    for i, bgr in ((0, cd_bgr), (2, login_bgr), (3, other), (4, cd_bgr)):
+        r = out[i]
+        g = fr.bgr2gray(bgr)
+        th = fr.threshold(g, 150, 255, 1)[1]
+        vl, hl = fr.morphology_ex(th, 2, (1, 15), 2), fr.morphology_ex(th, 2, (15, 1), 2)
+        assert np.array_equal(r.image, bgr) and np.array_equal(r.gray, g) and np.array_equal(r.thresh, th)
+        assert np.array_equal(r.vlines, vl) and np.array_equal(r.hlines, hl)
+        assert np.array_equal(np.asarray(r.vertical_segments, dtype=np.int64).reshape(-1, 4), fr.external_boxes(vl))
+        assert np.array_equal(np.asarray(r.horizontal_segments, dtype=np.int64).reshape(-1, 4), fr.external_boxes(hl))
