@@ -773,9 +773,16 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     // regions of at most HT_MAX_TILES tiles (64 x 64 tiles = 8192 x 2048 pixels)
     int rt_x = tiles_x, rt_y = tiles_y;
     if ((long long)rt_x * rt_y > HT_MAX_TILES) {
-        rt_x = tiles_x < 64 ? tiles_x : 64;
-        rt_y = HT_MAX_TILES / rt_x;
-        if (rt_y > tiles_y) rt_y = tiles_y;
+        // one workgroup per region: small regions keep the whole chip busy on a single large image,
+        // at the price of more rounds for chains that cross many of them
+        static int side = -1;  // IPA_HYST_REGION: region side in tiles (square of tiles; 1..64)
+        if (side < 0) {
+            const char* e = getenv("IPA_HYST_REGION");
+            side = e ? atoi(e) : 16;
+            if (side < 1 || side > 64) side = 16;
+        }
+        rt_x = tiles_x < side ? tiles_x : side;
+        rt_y = tiles_y < side ? tiles_y : side;
     }
     const int regions_x = cdiv(tiles_x, rt_x), regions_y = cdiv(tiles_y, rt_y);
     const long long blocks = (long long)regions_x * regions_y * batch;

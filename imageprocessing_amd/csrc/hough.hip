@@ -197,6 +197,8 @@ struct VoteArgs {
     int32_t* segmax;  // optional: per image, angle and 512-column segment the largest count
     int nsegs;        // segments per accumulator row
     int xcd_remap;    // 1: relabel workgroups so that an image's workgroups share an XCD
+    int dbg_only_grp;   // experiments: only this angle group votes (-1 = all)
+    u32 dbg_trip_mask;  // experiments: list trips wrapped into a small window (0xffffffff = off)
     u32 items;        // k_hough_vote_s: (image, angle group) work items = groups * images of the launch
 };
 
@@ -208,6 +210,9 @@ __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
 constexpr int VOTE_THREADS = 512;
 constexpr int HOUGH_SEG = VOTE_THREADS;  // columns per segment of the per-row maxima
 constexpr int VOTE_MAX_TG = 16;
+#ifndef VOTE_STAGGER_TRIPS
+#define VOTE_STAGGER_TRIPS 4
+#endif
 #ifndef VOTE_PREFETCH
 #define VOTE_PREFETCH 2
 #endif
@@ -352,8 +357,11 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 // each shared by two points) plus one shift-add for the LDS address.  NT = threads per
 // workgroup: every workgroup streams the image's whole point list (from L2), so more angles per
 // workgroup mean less list traffic, and 1024 threads keep the CU full with two such workgroups.
+// One angle per workgroup (TG = 1) is the shape of very large images, whose rho window only fits
+// once into a CU's LDS: that single workgroup has the registers of a whole CU, and it loads eight
+// trips ahead because nothing else on the CU hides the latency of its list.
 template <int TG, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))  // two 1024-thread workgroups per CU
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(TG == 1 ? 4 : 8, 8)))  // TG > 1: two 1024-thread workgroups per CU
 void k_hough_vote_s(VoteArgs A, Trig T)
 {
     extern __shared__ __align__(16) u32 hist[];
@@ -366,6 +374,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     const u32 wg = A.xcd_remap ? xcd_contiguous_id(item, A.items) : item;
     const int b = (int)(wg / (u32)A.groups);
     const int grp = (int)(wg - (u32)b * (u32)A.groups);
+    if (A.dbg_only_grp >= 0 && grp != A.dbg_only_grp) continue;
     const int n0 = grp * TG;
     const int tg = min(TG, A.numangle - n0);
     const int half = (A.numrho - 1) / 2;
@@ -387,7 +396,10 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         cg[g] = c;
         sg[g] = s;
         col0[g] = rmin + half + 1;
-        k4[g] = (u32)(half + 1 - col0[g] - 0x4B400000 + g * span) * 4u;
+        // one opaque scalar per angle, so that the bin address is a single shift-add
+        u32 k4g = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(half + 1 - col0[g] - 0x4B400000 + g * span) * 4u));
+        asm volatile("" : "+s"(k4g));  // keeps the compiler from splitting the sum again
+        k4[g] = k4g;
     }
     for (int i = tid; i < TG * span; i += NT) hist[i] = 0;
     __syncthreads();
@@ -401,9 +413,18 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     // Four consecutive list entries per lane and trip (one 16-byte load).  The loads run PF trips
     // ahead of the votes: the list comes from L2 when the workgroup has the chip to itself, but
     // from a busy HBM when a streaming kernel of another stream shares the CU.
-    constexpr int PF = VOTE_PREFETCH;
+    constexpr int PF = TG == 1 ? 8 : VOTE_PREFETCH;
     const u32 trips = nfull / NT;  // trips in which every lane has four points
-    auto load4 = [&](u32 trip) -> uint4 { return pts4[trip * NT + tid]; };
+    // Workgroups of one image walk the same list.  In lockstep they would all ask the same L2
+    // channel for the same lines at the same moment (measured on a single 16k x 16k image: the list
+    // arrives at 1.2 TB/s, one channel's worth per XCD), so every angle group starts a few trips
+    // further into the list and wraps around: neighbours still find each other's lines in L2.
+    const u32 rot = trips ? ((u32)grp * VOTE_STAGGER_TRIPS) % trips : 0u;
+    auto load4 = [&](u32 trip) -> uint4 {
+        u32 t = trip + rot;  // trip < trips
+        t = t >= trips ? t - trips : t;
+        return pts4[(t & A.dbg_trip_mask) * NT + tid];
+    };
     auto cast4 = [&](const uint4 cur) {
         const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
         const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
@@ -438,7 +459,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         for (int k = 0; k < PF; k++)
             if (i + k < trips) cast4(buf[k]);
     }
-    if (trips * NT + tid < nfull) cast4(load4(trips));
+    if (trips * NT + tid < nfull) cast4(pts4[trips * NT + tid]);
     const u32 tail0 = nfull * 4;
     // the points left over by the four-at-a-time loop
     for (u32 j = tail0 + tid; j < npts; j += NT) {
@@ -673,7 +694,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             T.c[n] = (float)(cos((double)ang) * irho);
         }
     }
-    static const bool revote = getenv("IPA_VOTE_ONLY") != nullptr;  // experiments: re-vote the lists of the previous call
+    const bool revote = getenv("IPA_VOTE_ONLY") != nullptr;  // experiments: re-vote the lists of the previous call
     if (phase != HOUGH_VOTE_ONLY && !revote) {
         IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
         ProfScope ps(PROF_HOUGH_COMPACT, st);
@@ -684,7 +705,10 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             cmode = e ? atoi(e) : 1;
         }
         if (cmode == 1) {
-            const dim3 grid((unsigned)batch, (unsigned)cdiv(cpr, 64 * ROWS_PER_LANE), (unsigned)cdiv(h, 4));
+            // The four rows of a block are gridDim.z apart.  An odd distance: rows a multiple of 32 apart
+            // (any height that is a multiple of 128) put the bins of theta = 90 degrees of all four into
+            // one LDS bank, and the vote kernel then serialises (measured: 10x on that angle).
+            const dim3 grid((unsigned)batch, (unsigned)cdiv(cpr, 64 * ROWS_PER_LANE), (unsigned)(cdiv(h, 4) | 1));
             static int spread = -1;  // IPA_COMPACT_SPREAD=0 keeps raster order inside a block
             if (spread < 0) {
                 const char* e = getenv("IPA_COMPACT_SPREAD");
@@ -819,6 +843,8 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
         Ab.items = (u32)A.groups * (u32)nb;
+        Ab.dbg_only_grp = getenv("IPA_VOTE_ONLY_GRP") ? atoi(getenv("IPA_VOTE_ONLY_GRP")) : -1;
+        Ab.dbg_trip_mask = getenv("IPA_VOTE_WRAP") ? (u32)atoi(getenv("IPA_VOTE_WRAP")) : 0xffffffffu;
         static int resident_env = -1;  // IPA_VOTE_RESIDENT: force a resident grid of that many workgroups (multiple of 8)
         if (resident_env < 0) {
             const char* e = getenv("IPA_VOTE_RESIDENT");
