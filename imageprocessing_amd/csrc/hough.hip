@@ -197,6 +197,7 @@ struct VoteArgs {
     int32_t* segmax;  // optional: per image, angle and 512-column segment the largest count
     int nsegs;        // segments per accumulator row
     int xcd_remap;    // 1: relabel workgroups so that an image's workgroups share an XCD
+    int slices;         // k_hough_vote_s: workgroups that share one (image, angle group); > 1: they add their bins to a zeroed accumulator
     int dbg_only_grp;   // experiments: only this angle group votes (-1 = all)
     u32 dbg_trip_mask;  // experiments: list trips wrapped into a small window (0xffffffff = off)
     u32 items;        // k_hough_vote_s: (image, angle group) work items = groups * images of the launch
@@ -372,8 +373,10 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     // a multiple of 8 then, so that a workgroup's items stay on its XCD.
   for (u32 item = blockIdx.x; item < A.items; item += gridDim.x) {
     const u32 wg = A.xcd_remap ? xcd_contiguous_id(item, A.items) : item;
-    const int b = (int)(wg / (u32)A.groups);
-    const int grp = (int)(wg - (u32)b * (u32)A.groups);
+    const u32 per_image = (u32)A.groups * (u32)A.slices;
+    const int b = (int)(wg / per_image);
+    const u32 rem = wg - (u32)b * per_image;
+    const int grp = (int)(rem / (u32)A.slices), slice = (int)(rem - (u32)grp * (u32)A.slices);
     if (A.dbg_only_grp >= 0 && grp != A.dbg_only_grp) continue;
     const int n0 = grp * TG;
     const int tg = min(TG, A.numangle - n0);
@@ -414,7 +417,12 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     // ahead of the votes: the list comes from L2 when the workgroup has the chip to itself, but
     // from a busy HBM when a streaming kernel of another stream shares the CU.
     constexpr int PF = TG == 1 ? 8 : VOTE_PREFETCH;
-    const u32 trips = nfull / NT;  // trips in which every lane has four points
+    // trips in which every lane has four points; a slice takes its share of them, the last slice
+    // also what is left over behind them
+    const u32 all_trips = nfull / NT;
+    const u32 trip0 = (u32)((unsigned long long)all_trips * (u32)slice / (u32)A.slices);
+    const u32 trips = (u32)((unsigned long long)all_trips * (u32)(slice + 1) / (u32)A.slices) - trip0;
+    const bool last_slice = slice == A.slices - 1;
     // Workgroups of one image walk the same list.  In lockstep they would all ask the same L2
     // channel for the same lines at the same moment (measured on a single 16k x 16k image: the list
     // arrives at 1.2 TB/s, one channel's worth per XCD), so every angle group starts a few trips
@@ -423,7 +431,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     auto load4 = [&](u32 trip) -> uint4 {
         u32 t = trip + rot;  // trip < trips
         t = t >= trips ? t - trips : t;
-        return pts4[(t & A.dbg_trip_mask) * NT + tid];
+        return pts4[(trip0 + (t & A.dbg_trip_mask)) * NT + tid];
     };
     auto cast4 = [&](const uint4 cur) {
         const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
@@ -459,8 +467,8 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         for (int k = 0; k < PF; k++)
             if (i + k < trips) cast4(buf[k]);
     }
-    if (trips * NT + tid < nfull) cast4(pts4[trips * NT + tid]);
-    const u32 tail0 = nfull * 4;
+    if (last_slice && all_trips * NT + tid < nfull) cast4(pts4[all_trips * NT + tid]);
+    const u32 tail0 = last_slice ? nfull * 4 : npts;
     // the points left over by the four-at-a-time loop
     for (u32 j = tail0 + tid; j < npts; j += NT) {
         const u32 p = pts[j];
@@ -477,9 +485,18 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         if (g < tg) {
             int32_t* row = acc + (size_t)(n0 + g + 1) * ncols;
             const u32* hg = hist + g * span;
-            for (int col = tid; col < ncols; col += NT) {
-                const int idx = col - col0[g];
-                row[col] = (unsigned)idx < (unsigned)span ? (int32_t)hg[idx] : 0;
+            if (A.slices == 1) {
+                for (int col = tid; col < ncols; col += NT) {
+                    const int idx = col - col0[g];
+                    row[col] = (unsigned)idx < (unsigned)span ? (int32_t)hg[idx] : 0;
+                }
+            } else {
+                // the accumulator was zeroed before the launch; slices add what they counted
+                for (int idx = tid; idx < span; idx += NT) {
+                    const u32 v = hg[idx];
+                    const int col = idx + col0[g];
+                    if (v && col < ncols) atomicAdd(&row[col], (int32_t)v);
+                }
             }
         }
     }
@@ -504,9 +521,9 @@ void k_hough_vote_s(VoteArgs A, Trig T)
             if (lane == 0) sm[q] = (int32_t)mx;
         }
     }
-    if (grp == 0)
+    if (A.slices == 1 && grp == 0)
         for (int col = tid; col < ncols; col += NT) acc[col] = 0;
-    if (grp == A.groups - 1)
+    if (A.slices == 1 && grp == A.groups - 1)
         for (int col = tid; col < ncols; col += NT) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
     __syncthreads();  // the bins are cleared again for the next item
   }
@@ -613,6 +630,27 @@ __global__ __launch_bounds__(256) void k_hough_peaks_seg(const int32_t* __restri
         }
       }
     }
+}
+
+// Largest count of every HOUGH_SEG-column segment of every accumulator row, for the launches whose
+// vote kernel cannot leave it behind (several workgroups add into one row).  One wave per segment.
+__global__ __launch_bounds__(256) void k_hough_segmax(const int32_t* __restrict__ accum, size_t accum_stride, int numangle,
+                                                      int numrho, int nsegs, int32_t* __restrict__ segmax)
+{
+    const int b = blockIdx.z, n = blockIdx.y;
+    const int j = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= nsegs) return;
+    const int ncols = numrho + 2;
+    const int32_t* row = accum + (size_t)b * accum_stride + (size_t)(n + 1) * ncols;
+    int32_t mx = 0;
+#pragma unroll
+    for (int t = 0; t < HOUGH_SEG / 64; t++) {
+        const int col = j * HOUGH_SEG + t * 64 + lane;
+        if (col < ncols) mx = max(mx, row[col]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 0) segmax[((size_t)b * numangle + n) * nsegs + j] = mx;
 }
 
 void hough_dims(int w, int h, double rho, double theta, int* numangle, int* numrho)
@@ -812,8 +850,27 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     }
     A.xcd_remap = remap;
     A.nsegs = hough_segments(numrho);
-    A.segmax = tgs ? seg_max : nullptr;
-    if (seg_max && !tgs)  // this kernel variant does not produce the maxima: mark every segment as worth reading
+    // Few large images: (image, angle group) alone gives too few workgroups to fill the chip, and one
+    // angle whose votes pile up on a few bins (theta = 90 degrees on ruled paper) holds everything
+    // up.  The list is then cut into slices, one workgroup each, which add into a zeroed accumulator.
+    A.slices = 1;
+    if (tgs && resident_wgs == 0) {
+        static int slices_env = -1;  // IPA_VOTE_SLICES: 0 = automatic
+        if (slices_env < 0) {
+            const char* e = getenv("IPA_VOTE_SLICES");
+            slices_env = e ? atoi(e) : 0;
+        }
+        const long long wgs = (long long)A.groups * batch;
+        if (slices_env > 0) A.slices = slices_env > 64 ? 64 : slices_env;
+        else if ((long long)w * h >= (1 << 22) && wgs < 768) A.slices = (int)(1536 / wgs > 16 ? 16 : 1536 / wgs);
+        if (A.slices < 1) A.slices = 1;
+    }
+    if (A.slices > 1)
+        for (int b = 0; b < batch; b++)
+            IPA_HIP(hipMemsetAsync(accum + (size_t)b * accum_stride, 0, sizeof(int32_t) * (size_t)(numangle + 2) * (numrho + 2), st));
+    A.segmax = (tgs && A.slices == 1) ? seg_max : nullptr;
+    const bool segmax_after = seg_max && A.slices > 1;  // computed from the finished accumulator
+    if (seg_max && !A.segmax && !segmax_after)  // this kernel variant does not produce the maxima: mark every segment as worth reading
         IPA_HIP(hipMemsetD32Async((hipDeviceptr_t)seg_max, 0x7fffffff, (size_t)batch * numangle * A.nsegs, st));
     size_t lds = (size_t)tg * span_words * 4 + lds_pad_kib("IPA_PAD_VOTE");
     // a resident grid must not get two workgroups onto one CU: more than half of the CU's LDS each
@@ -842,7 +899,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.accum = accum + (size_t)b0 * accum_stride;
         if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
-        Ab.items = (u32)A.groups * (u32)nb;
+        Ab.items = (u32)A.groups * (u32)A.slices * (u32)nb;
         Ab.dbg_only_grp = getenv("IPA_VOTE_ONLY_GRP") ? atoi(getenv("IPA_VOTE_ONLY_GRP")) : -1;
         Ab.dbg_trip_mask = getenv("IPA_VOTE_WRAP") ? (u32)atoi(getenv("IPA_VOTE_WRAP")) : 0xffffffffu;
         static int resident_env = -1;  // IPA_VOTE_RESIDENT: force a resident grid of that many workgroups (multiple of 8)
@@ -873,6 +930,15 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         else
             hipLaunchKernelGGL((k_hough_vote<false, true>), grid, block, lds, st, Ab, T);
         IPA_LAUNCH_CHECK();
+    }
+    if (segmax_after) {
+        for (int b0 = 0; b0 < batch; b0 += 65535) {
+            const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            hipLaunchKernelGGL(k_hough_segmax, dim3((unsigned)cdiv(A.nsegs, 4), (unsigned)numangle, (unsigned)nb), dim3(256), 0, st,
+                               accum + (size_t)b0 * accum_stride, accum_stride, numangle, numrho, A.nsegs,
+                               seg_max + (size_t)b0 * numangle * A.nsegs);
+            IPA_LAUNCH_CHECK();
+        }
     }
     return IPA_OK;
 }

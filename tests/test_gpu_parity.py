@@ -444,6 +444,23 @@ def test_front_end_large_batch_runs_in_chunks(n, hough):
         _check_front_end(single, batch[i], 140, 15, 15, 2, 50, 150, False)
 
 
+def test_hough_single_large_image_uses_list_slices():
+    # a single image of >= 4 Mpx: the point list is cut into slices that add into a zeroed accumulator
+    bgr = uml_like(77, 2048, 2176)
+    e = fr.canny(fr.bgr2gray(bgr), 50, 150)
+    acc, seg = cv2.hough_accumulator(e, 1, np.pi / 180, with_seg_max=True)
+    ref = fr.hough_accum(e, 1, np.pi / 180)
+    assert np.array_equal(acc.cpu().numpy(), ref)
+    sg, rows = seg.cpu().numpy(), ref[1:-1]
+    for j in range(sg.shape[1]):  # the maxima come from a pass over the finished accumulator here
+        assert np.array_equal(sg[:, j], rows[:, j * 512 : (j + 1) * 512].max(axis=1))
+    for thr in (150, 400):
+        got, want = cv2.HoughLines(e, 1, np.pi / 180, thr), fr.hough_lines(e, 1, np.pi / 180, thr)
+        assert (got is None) == (want is None)
+        if want is not None:
+            assert np.array_equal(got, want)
+
+
 def test_front_end_1080p_config1():
     # BASELINE config 1: one 1920x1080 class-diagram raster, seed 1000, 12 boxes
     bgr = uml_like(1000, 1080, 1920)
