@@ -739,3 +739,44 @@ def test_process_files_matches_the_per_file_loop(cd_bgr, login_bgr):
         assert np.array_equal(r.vlines, vl) and np.array_equal(r.hlines, hl)
         assert np.array_equal(np.asarray(r.vertical_segments, dtype=np.int64).reshape(-1, 4), fr.external_boxes(vl))
         assert np.array_equal(np.asarray(r.horizontal_segments, dtype=np.int64).reshape(-1, 4), fr.external_boxes(hl))
+
+
+# ------------------------------------------------------------------ degenerate shapes
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 7), (7, 1), (2, 2), (3, 33), (33, 3)])
+def test_every_op_on_tiny_images(h, w):
+    rng = np.random.default_rng(h * 100 + w)
+    g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    assert np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), fr.bgr2gray(bgr))
+    assert np.array_equal(cv2.threshold(g, 100, 255, cv2.THRESH_BINARY_INV)[1], fr.threshold(g, 100, 255, 1)[1])
+    t, d = cv2.threshold(g, 0, 255, cv2.THRESH_BINARY + cv2.THRESH_OTSU)
+    to, do = fr.threshold(g, 0, 255, 8)
+    assert t == to and np.array_equal(d, do)
+    k = cv2.getStructuringElement(cv2.MORPH_RECT, (15, 1))
+    for op in (cv2.MORPH_OPEN, cv2.MORPH_CLOSE):
+        assert np.array_equal(cv2.morphologyEx(g, op, k, iterations=2), fr.morphology_ex(g, op, (15, 1), 2))
+    assert np.array_equal(cv2.erode(g, np.ones((3, 3), np.uint8)), fr.morphology_ex(g, 0, (3, 3), 1))
+    assert np.array_equal(cv2.GaussianBlur(g, (5, 5), 0), fr.gaussian_blur(g, (5, 5), 0))
+    assert np.array_equal(cv2.adaptiveThreshold(g, 255, cv2.ADAPTIVE_THRESH_GAUSSIAN_C, cv2.THRESH_BINARY, 11, 2),
+                          fr.adaptive_threshold(g, 255, 1, 0, 11, 2))
+    e = cv2.Canny(g, 50, 150)
+    assert np.array_equal(e, fr.canny(g, 50, 150))
+    assert np.array_equal(cv2.hough_accumulator(e, 1, np.pi / 180).cpu().numpy(), fr.hough_accum(e, 1, np.pi / 180))
+    assert np.array_equal(cv2.bitwise_not(g), 255 - g)
+    res = cv2.front_end(bgr)
+    _check_front_end(res, bgr, 128, 15, 15, 2, 50, 150, False)
+    _seg_same(cv2.get_segments(g), g)
+    _hp_same(g, 1, np.pi / 180, 1, 0, 0)
+
+
+def test_empty_inputs_come_back_empty():
+    # cv2 rejects empty images; here they pass through as empty results (no kernel is launched)
+    for shape in ((0, 0), (0, 5), (5, 0)):
+        g = np.zeros(shape, np.uint8)
+        assert cv2.threshold(g, 1, 255, 0)[1].shape == shape
+        assert cv2.Canny(g, 50, 150).shape == shape
+        assert cv2.cvtColor(np.zeros(shape + (3,), np.uint8), cv2.COLOR_BGR2GRAY).shape == shape
+        assert cv2.get_segments(g) == []
+        assert cv2.HoughLinesP(g, 1, np.pi / 180, 1) is None
+    assert cv2.front_end_batch(np.zeros((0, 8, 8, 3), np.uint8)).gray.shape == (0, 8, 8)
+    assert cv2.segments_batch(np.zeros((0, 8, 8), np.uint8)) == []
