@@ -780,3 +780,17 @@ def test_empty_inputs_come_back_empty():
         assert cv2.HoughLinesP(g, 1, np.pi / 180, 1) is None
     assert cv2.front_end_batch(np.zeros((0, 8, 8, 3), np.uint8)).gray.shape == (0, 8, 8)
     assert cv2.segments_batch(np.zeros((0, 8, 8), np.uint8)) == []
+
+
+def test_hough_lines_p_under_load():
+    # 160 waves side by side on accumulators that do not fit the caches: the memory-ordering
+    # assumptions of the one-wave-per-image kernel (list, mask and accumulator through L2) must hold
+    base = [fr.canny(fr.bgr2gray(uml_like(900 + i, 720, 1280)), 50, 150) for i in range(8)]
+    imgs = np.stack([base[i % 8] for i in range(160)])
+    got = cv2.hough_lines_p_batch(imgs, 1, np.pi / 180, 80, minLineLength=60, maxLineGap=8)
+    want = [fr.hough_lines_p(b, 1, np.pi / 180, 80, 60, 8) for b in base]
+    for i in range(160):
+        wv = want[i % 8]
+        assert (got[i] is None) == (wv is None), i
+        if wv is not None:
+            assert np.array_equal(got[i], wv), i
