@@ -274,18 +274,20 @@ bool fused_points()
     return fused != 0;
 }
 
-// [GaussianBlur] + Canny; with a Hough stage behind it also the lists of edge pixels
+// GaussianBlur 5x5 of the gray plane into the chunk's scratch plane (variant with blur only)
+int stage_blur(const Chunk& C, hipStream_t st)
+{
+    if (!C.blur5x5) return IPA_OK;
+    Plane BL = mkplane(C.blur_plane, C.L.blur_pitch, C.L.blur_pitch * (size_t)C.height);
+    ProfScope ps(PROF_BLUR, st);
+    return launch_gauss5(C.G, BL, C.width, C.height, C.batch, C.blur_ws, C.L.blur_ws_bytes, st);
+}
+
+// Canny (of the blurred plane if there is one); with a Hough stage behind it also the lists of edge pixels
 int stage_edges(const Chunk& C, bool with_lists, hipStream_t st)
 {
     int rc;
-    Plane csrc = C.G;
-    if (C.blur5x5) {
-        Plane BL = mkplane(C.blur_plane, C.L.blur_pitch, C.L.blur_pitch * (size_t)C.height);
-        ProfScope ps(PROF_BLUR, st);
-        rc = launch_gauss5(C.G, BL, C.width, C.height, C.batch, C.blur_ws, C.L.blur_ws_bytes, st);
-        if (rc) return rc;
-        csrc = BL;
-    }
+    const Plane csrc = C.blur5x5 ? mkplane(C.blur_plane, C.L.blur_pitch, C.L.blur_pitch * (size_t)C.height) : C.G;
     PointSink sink = {nullptr, 0, 0, nullptr};
     if (C.accum && fused_points()) {
         sink = hough_point_sink(C.width, C.height, C.max_points, C.point_counts, C.hough_ws);
@@ -356,6 +358,7 @@ static int front_end_chunk(const Chunk& C, hipStream_t st, hipEvent_t after_gray
     if (so && stream_after(so, st, E) != IPA_OK) so = nullptr;
     if (!so) so = st;
     rc = stage_opens(C, so);
+    if (!rc) rc = stage_blur(C, st);
     if (!rc) rc = stage_edges(C, false, st);
     if (!rc) rc = stage_vote(C, false, 0, st);
     // join, also after an error: the caller's stream waits for the opens
@@ -428,6 +431,7 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
         rc = stage_gray(C[0], st);
         if (!rc) rc = stream_after(s2, st, E);
         if (!rc) rc = stage_opens(C[0], s2);
+        if (!rc) rc = stage_blur(C[0], st);
         for (int c = 0; c < nk && !rc; c++) {
             rc = stage_edges(C[c], true, st);
             if (rc) break;
@@ -440,7 +444,8 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
             rc = stage_vote(C[c], true, more ? cus : 0, st);
             if (rc || !more) break;
             rc = stage_gray(C[c + 1], s2);
-            if (!rc) rc = stream_after(st, s2, E);  // the next Canny needs this gray plane, not the opens
+            if (!rc) rc = stage_blur(C[c + 1], s2);  // bound by HBM like the gray kernel: beside the vote as well
+            if (!rc) rc = stream_after(st, s2, E);  // the next Canny needs the gray (blurred) plane, not the opens
             if (!rc) rc = stage_opens(C[c + 1], s2);
         }
     } else {
