@@ -219,10 +219,10 @@ __global__ __launch_bounds__(256) void k_seg_boxes(const u32* __restrict__ bits,
     const int b = blockIdx.y;
     const int32_t tot = A.total[b];
     if (tot < 0) return;
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (u32)tot) return;
     const size_t base = (size_t)b * A.cap;
     u32* parent = A.parent + base;
+  // the grid is sized for a typical mask, not for the capacity: workgroups walk the segments
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (u32)tot; i += gridDim.x * 256u) {
     const u32 r = seg_find(parent, i);
     if (r != i) parent[i] = r;  // roots never change once the unions are done
     const u32 y = A.yy[base + i];
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void k_seg_boxes(const u32* __restrict__ bits,
     } else if (y == 0 || y == (u32)h - 1 || sx == 0 || ex == (u32)w - 1) {
         if (!(__builtin_nontemporal_load(&A.flags[base + r]) & SEG_OUTSIDE)) atomicOr(&A.flags[base + r], SEG_OUTSIDE);
     }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_seg_extern(const u32* __restrict__ bits, size_t bpw, size_t bsw, int w, int h,
@@ -248,15 +249,14 @@ __global__ __launch_bounds__(256) void k_seg_extern(const u32* __restrict__ bits
     const int b = blockIdx.y;
     const int32_t tot = A.total[b];
     if (tot < 0) return;
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (u32)tot) return;
     const size_t base = (size_t)b * A.cap;
     const u32* off = A.rowoff + (size_t)b * (h + 1);
     const u32* xs = A.xs + base;
     const u32* parent = A.parent + base;
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (u32)tot; i += gridDim.x * 256u) {
     const u32 y = A.yy[base + i];
     const u32 f = off[y], n = off[y + 1] - f, k = i - f;
-    if (!seg_value(bits, bpw, bsw, b, (int)y, k)) return;  // foreground segments only
+    if (!seg_value(bits, bpw, bsw, b, (int)y, k)) continue;  // foreground segments only
     const u32 sx = xs[i], ex = (k + 1 < n ? xs[i + 1] : (u32)w) - 1u;
     bool ext = y == 0 || y == (u32)h - 1 || sx == 0 || ex == (u32)w - 1;
     auto outside = [&](u32 seg) -> bool { return (A.flags[base + parent[seg]] & SEG_OUTSIDE) != 0; };
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_seg_extern(const u32* __restrict__ bits
     }
     if (ext && !(__builtin_nontemporal_load(&A.flags[base + parent[i]]) & SEG_EXTERNAL))
         atomicOr(&A.flags[base + parent[i]], SEG_EXTERNAL);
+  }
 }
 
 // one workgroup per image: external foreground roots, largest index first
@@ -391,7 +392,7 @@ IPA_EXPORT int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t ma
         B.x0 += (size_t)b0 * cap; B.x1 += (size_t)b0 * cap; B.y1 += (size_t)b0 * cap; B.flags += (size_t)b0 * cap;
         B.total += b0;
         const u32* bb = bits + (size_t)b0 * bsw;
-        const dim3 rows((unsigned)cdiv(height, 4), (unsigned)nb), segs((unsigned)cdiv((long long)cap, 256), (unsigned)nb);
+        const dim3 rows((unsigned)cdiv(height, 4), (unsigned)nb), segs((unsigned)(cdiv((long long)cap, 256) < 64 ? cdiv((long long)cap, 256) : 64), (unsigned)nb);
         hipLaunchKernelGGL(k_seg_count, rows, dim3(256), 0, st, bb, bpw, bsw, width, height, B);
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)nb), dim3(1024), 0, st, height, B);
         hipLaunchKernelGGL(k_seg_fill, rows, dim3(256), 0, st, bb, bpw, bsw, width, height, B);
