@@ -108,17 +108,23 @@ __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane b
         if (PACK) rowbits[i] = mybits;
     }
     if (PACK) {
-        // The wave's bits of its four rows are 4 x 128 bytes of the bit plane.  They go through
-        // LDS so that ONE store instruction writes them (lane L: the 8 bytes of chunk columns
-        // 4(L%16)..4(L%16)+3 of row L/16) instead of a half-empty store per row.
-        __shared__ unsigned short s_bits[4][ROWS_PER_LANE][64];
-        const int wv = threadIdx.y, lane = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < ROWS_PER_LANE; i++) s_bits[wv][i][lane] = (unsigned short)rowbits[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int r = lane >> 4, c0 = (lane & 15) * 4;
-        const uint2 v = *(const uint2*)&s_bits[wv][r][c0];
+        // The wave's bits of its four rows are 4 x 128 bytes of the bit plane.  A 4 x 4 transposition
+        // of 16-bit items inside every quad of lanes (two DPP exchanges, no LDS: this kernel runs
+        // beside the vote kernel, whose atomics keep the LDS queue full) leaves lane 4q + r with the
+        // 64 bits of row r, chunk columns 4q .. 4q+3, so that ONE store instruction writes everything:
+        // every row gets 16 lanes x 8 contiguous bytes.
+        static_assert(ROWS_PER_LANE == 4, "quad transposition");
+        const int lane = threadIdx.x;
+        const u32 p01 = rowbits[0] | (rowbits[1] << 16), p23 = rowbits[2] | (rowbits[3] << 16);
+        const u32 o01 = (u32)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+        const u32 o23 = (u32)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xf, 0xf, true);
+        const u32 sel = (lane & 1) ? 0x03020706u : 0x05040100u;  // odd lanes keep the odd rows
+        const u32 q01 = __builtin_amdgcn_perm(o01, p01, sel), q23 = __builtin_amdgcn_perm(o23, p23, sel);
+        const bool upper = (lane & 2) != 0;  // lanes 2, 3 of a quad end up with rows 2, 3
+        const u32 send = upper ? q01 : q23;
+        const u32 recv = (u32)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);  // lane ^ 2
+        const uint2 v = make_uint2(upper ? recv : q01, upper ? q23 : recv);
+        const int r = lane & 3, c0 = (lane >> 2) * 4;
         const int yy = y0 + r, cc = blockIdx.x * 64 + c0;
         if (yy < h && cc < cpr) *(uint2*)((u8*)(bits + (size_t)b * bsw + (size_t)yy * bpw) + (size_t)cc * 2) = v;
     }
