@@ -298,6 +298,17 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launch_ms": stages[dom]["ms"], "algorithmic_bytes_per_launch": alg[dom] * batch}
+            if dom == "hough_vote" and fe.hough:
+                # the vote is bound by LDS atomics, not by HBM: also quote it against the LDS atomic rate
+                # measured on this chip for random addresses (scripts/micro/lds_big.hip: 1024 x 20000
+                # ds_add_u32 lanes per CU in 1.03 ms = 19.9e9 lane-atomics per second and CU)
+                props = torch.cuda.get_device_properties(dev)
+                votes = float(fe.point_counts[:batch].sum().item()) * fe.na
+                ceiling = 19.9e9 * props.multi_processor_count
+                rate = votes / (stages[dom]["ms"] * 1e-3)
+                roof["lds_atomics"] = {"votes_per_s": round(rate, 0), "ceiling_votes_per_s": round(ceiling, 0),
+                                       "frac": round(rate / ceiling, 4),
+                                       "note": "180 votes per edge pixel, one ds_add_u32 lane each; ceiling = measured random-address rate"}
         cpu = None
         if not args.no_cpu:
             try:
