@@ -794,3 +794,40 @@ def test_hough_lines_p_under_load():
         assert (got[i] is None) == (wv is None), i
         if wv is not None:
             assert np.array_equal(got[i], wv), i
+
+
+# ------------------------------------------------------------------ the C ABI itself
+def test_c_abi_error_codes_streams_and_const_inputs():
+    # raw calls through ctypes: error codes instead of faults, work on a caller-chosen stream,
+    # inputs left untouched
+    from imageprocessing_amd import _native
+
+    L = _native.lib()
+    h, w, n = 40, 64, 3
+    pitch = int(L.ipa_pitch_for(w))
+    src = torch.randint(0, 256, (n, h, pitch), dtype=torch.uint8, device="cuda")
+    keep = src.clone()
+    dst = torch.empty_like(src)
+    wsn = int(L.ipa_canny_workspace_bytes(w, h, n))
+    ws = torch.empty(wsn + 256, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    sp = stream.cuda_stream
+    args = lambda s_ptr, s_pitch, ws_ptr, ws_bytes: (s_ptr, s_pitch, h * pitch, dst.data_ptr(), pitch, h * pitch, w, h, n, 50.0, 150.0,
+                                                     ws_ptr, ws_bytes, sp)
+    assert L.ipa_canny_u8(*args(src.data_ptr(), pitch, ws.data_ptr(), wsn)) == 0
+    stream.synchronize()
+    for i in range(n):
+        assert np.array_equal(dst[i, :, :w].cpu().numpy(), fr.canny(keep[i, :, :w].cpu().numpy(), 50, 150))
+    assert torch.equal(src, keep)
+    assert L.ipa_canny_u8(*args(src.data_ptr() + 1, pitch, ws.data_ptr(), wsn)) == -2          # IPA_ERR_ALIGN
+    assert L.ipa_canny_u8(*args(src.data_ptr(), w - 16, ws.data_ptr(), wsn)) == -2             # pitch < row bytes
+    assert L.ipa_canny_u8(*args(src.data_ptr(), pitch, ws.data_ptr(), 16)) == -3               # IPA_ERR_WORKSPACE
+    assert b"workspace" in L.ipa_last_error()
+    assert L.ipa_canny_u8(*args(src.data_ptr(), pitch, None, wsn)) == -3
+    assert L.ipa_morph_u8(src.data_ptr(), pitch, h * pitch, dst.data_ptr(), pitch, h * pitch, w, h, n, 7, 3, 3, -1, -1, 1, 0,
+                          ws.data_ptr(), wsn, sp) == -1                                         # unknown morphology op
+    assert L.ipa_segments_u8(src.data_ptr(), pitch, h * pitch, w, h, n, 0, None, 8, None, ws.data_ptr(), wsn, sp) == -1
+    # zero-sized work is a successful no-op
+    assert L.ipa_canny_u8(src.data_ptr(), pitch, h * pitch, dst.data_ptr(), pitch, h * pitch, 0, h, n, 50.0, 150.0, None, 0, sp) == 0
+    assert L.ipa_canny_u8(src.data_ptr(), pitch, h * pitch, dst.data_ptr(), pitch, h * pitch, w, h, 0, 50.0, 150.0, None, 0, sp) == 0
+    torch.cuda.synchronize()
