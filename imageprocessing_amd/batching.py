@@ -68,23 +68,68 @@ def group_by_shape(images: Sequence[Optional[np.ndarray]], max_batch: int = 256)
     return {k: [v[o : o + max_batch] for o in range(0, len(v), max_batch)] for k, v in by_shape.items()}
 
 
-def process_images(images: Sequence[Optional[np.ndarray]], thresh_val: int = 128, vert_len: int = 15, horiz_len: int = 15,
-                   iterations: int = 2, segments: bool = True, max_batch: int = 256) -> List[Optional[ParsedImage]]:
-    """The parsers' prefix for many images at once.  ``thresh_val``: 150 class, 128 sequence /
-    activity, 100 state diagrams (umlClassdiagram.py:19, umlSequencediagram.py:22,
-    umlActivitydiagram.py:34, umlStateDiagram.py:19).  Undecodable entries stay None."""
+def _run_group(images, idx, thresh_val, vert_len, horiz_len, iterations, segments, stream):
+    import torch
+
     from . import pipeline
 
+    with torch.cuda.stream(stream):
+        stack = np.stack([images[i] for i in idx])
+        res = pipeline.front_end_batch(stack, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
+                                       iterations=iterations, hough=False)
+        vseg = pipeline.segments_batch(res.vlines) if segments else [None] * len(idx)
+        hseg = pipeline.segments_batch(res.hlines) if segments else [None] * len(idx)
+    return [(i, ParsedImage(images[i], res.gray[k], res.thresh[k], res.vlines[k], res.hlines[k], vseg[k], hseg[k]))
+            for k, i in enumerate(idx)]
+
+
+def process_images(images: Sequence[Optional[np.ndarray]], thresh_val: int = 128, vert_len: int = 15, horiz_len: int = 15,
+                   iterations: int = 2, segments: bool = True, max_batch: int = 256, overlap: int = 3) -> List[Optional[ParsedImage]]:
+    """The parsers' prefix for many images at once.  ``thresh_val``: 150 class, 128 sequence /
+    activity, 100 state diagrams (umlClassdiagram.py:19, umlSequencediagram.py:22,
+    umlActivitydiagram.py:34, umlStateDiagram.py:19).  Undecodable entries stay None.
+
+    ``overlap`` device batches are in flight at once, each on a stream of its own and driven by a
+    host thread of its own, so that the upload of one batch, the kernels of another and the
+    download of a third share the PCIe link and the GPU (a lone batch is bound by its copies)."""
+    import torch
+
     out: List[Optional[ParsedImage]] = [None] * len(images)
-    for _, batches in group_by_shape(images, max_batch).items():
-        for idx in batches:
-            stack = np.stack([images[i] for i in idx])
-            res = pipeline.front_end_batch(stack, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
-                                           iterations=iterations, hough=False)
-            vseg = pipeline.segments_batch(res.vlines) if segments else [None] * len(idx)
-            hseg = pipeline.segments_batch(res.hlines) if segments else [None] * len(idx)
-            for k, i in enumerate(idx):
-                out[i] = ParsedImage(images[i], res.gray[k], res.thresh[k], res.vlines[k], res.hlines[k], vseg[k], hseg[k])
+    work = [idx for _, batches in group_by_shape(images, max_batch).items() for idx in batches]
+    if not work:
+        return out
+    args = (thresh_val, vert_len, horiz_len, iterations, segments)
+    if overlap <= 1 or len(work) == 1:
+        done = [_run_group(images, idx, *args, torch.cuda.current_stream()) for idx in work]
+    else:
+        from . import _device
+
+        dev = _device._device()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(min(int(overlap), len(work)))]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+
+        import queue
+
+        free = queue.Queue()
+        for st in streams:
+            free.put(st)
+
+        def job(k):
+            st = free.get()  # one batch per stream at a time
+            try:
+                with torch.cuda.device(dev):
+                    r = _run_group(images, work[k], *args, st)
+                    st.synchronize()
+                    return r
+            finally:
+                free.put(st)
+
+        with ThreadPoolExecutor(max_workers=len(streams)) as pool:
+            done = list(pool.map(job, range(len(work))))
+    for group in done:
+        for i, parsed in group:
+            out[i] = parsed
     return out
 
 
