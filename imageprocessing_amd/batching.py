@@ -71,16 +71,26 @@ def group_by_shape(images: Sequence[Optional[np.ndarray]], max_batch: int = 256)
 def _run_group(images, idx, thresh_val, vert_len, horiz_len, iterations, segments, stream):
     import torch
 
-    from . import pipeline
+    from . import _device, pipeline
 
+    n = len(idx)
+    h, w = images[idx[0]].shape[:2]
     with torch.cuda.stream(stream):
-        stack = np.stack([images[i] for i in idx])
-        res = pipeline.front_end_batch(stack, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
+        # page-locked staging both ways; the planes stay on the device between the fused pass and the
+        # segment passes and come back in one copy
+        pin = torch.empty((n, h, w, 3), dtype=torch.uint8, pin_memory=True)
+        np.stack([images[i] for i in idx], out=pin.numpy())
+        dev_in = pin.to(_device._device(), non_blocking=True)
+        res = pipeline.front_end_batch(dev_in, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
                                        iterations=iterations, hough=False)
-        vseg = pipeline.segments_batch(res.vlines) if segments else [None] * len(idx)
-        hseg = pipeline.segments_batch(res.hlines) if segments else [None] * len(idx)
-    return [(i, ParsedImage(images[i], res.gray[k], res.thresh[k], res.vlines[k], res.hlines[k], vseg[k], hseg[k]))
-            for k, i in enumerate(idx)]
+        back = torch.empty((4, n, h, w), dtype=torch.uint8, pin_memory=True)
+        for k, plane in enumerate((res.gray, res.thresh, res.vlines, res.hlines)):
+            back[k].copy_(plane, non_blocking=True)
+        vseg = pipeline.segments_batch(res.vlines) if segments else [None] * n
+        hseg = pipeline.segments_batch(res.hlines) if segments else [None] * n
+        stream.synchronize()
+    host = back.numpy()
+    return [(i, ParsedImage(images[i], host[0, k], host[1, k], host[2, k], host[3, k], vseg[k], hseg[k])) for k, i in enumerate(idx)]
 
 
 def process_images(images: Sequence[Optional[np.ndarray]], thresh_val: int = 128, vert_len: int = 15, horiz_len: int = 15,
