@@ -302,6 +302,25 @@ def hough_peaks(acc: torch.Tensor, threshold: int, capacity: int = 4096, seg_max
         capacity = n
 
 
+def hough_peaks_batch(acc: torch.Tensor, threshold: int, capacity: int = 4096, seg_max: torch.Tensor = None):
+    """Unsorted peak keys of a batch of accumulators int32[N, numangle+2, numrho+2] in ONE device call:
+    list of N uint64 arrays."""
+    L = _native.lib()
+    n, na, nr = acc.shape[0], acc.shape[1] - 2, acc.shape[2] - 2
+    if n == 0:
+        return []
+    while True:
+        keys = torch.empty((n, max(capacity, 1)), dtype=torch.int64, device=acc.device)
+        cnt = torch.zeros(n, dtype=torch.int32, device=acc.device)
+        check(L.ipa_hough_peaks_i32(acc.data_ptr(), acc.stride(0), seg_max.data_ptr() if seg_max is not None else None, na, nr, n,
+                                    int(threshold), keys.data_ptr(), capacity, cnt.data_ptr(), stream_ptr()))
+        c = cnt.cpu().numpy()
+        if c.max(initial=0) <= capacity:
+            host = keys.cpu().numpy().view(np.uint64)
+            return [host[i, : int(c[i])].copy() for i in range(n)]
+        capacity = int(c.max())
+
+
 def HoughLines(image, rho, theta, threshold, lines=None, srn=0, stn=0, min_theta=0, max_theta=np.pi):
     """cv2.HoughLines(image, rho, theta, threshold) -> float32[N,1,2] or None
     ("New Version/comparison.py":20,30)."""

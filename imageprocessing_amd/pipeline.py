@@ -103,11 +103,8 @@ class FrontEnd:
 
     def lines(self, threshold: int):
         """Per-image cv2.HoughLines output from the accumulators of the last run."""
-        out = []
-        for b in range(self.batch):
-            keys = cv2api.hough_peaks(self.accum[b], int(threshold), seg_max=self.seg_max[b])
-            out.append(cv2api.lines_from_keys(keys, self.nr, 1.0, np.pi / 180) if keys.size else None)
-        return out
+        allkeys = cv2api.hough_peaks_batch(self.accum[: self.batch], int(threshold), seg_max=self.seg_max[: self.batch])
+        return [cv2api.lines_from_keys(k, self.nr, 1.0, np.pi / 180) if k.size else None for k in allkeys]
 
 
 def _result(fe: FrontEnd, like, squeeze: bool, hough_threshold) -> FrontEndResult:

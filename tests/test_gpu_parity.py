@@ -461,6 +461,20 @@ def test_hough_single_large_image_uses_list_slices():
             assert np.array_equal(got, want)
 
 
+def test_front_end_batch_line_lists():
+    # one batched peak search for the whole batch; every image's (rho, theta) list as cv2 orders it
+    n, h, w = 7, 200, 320
+    batch = np.stack([uml_like(4100 + i, h, w) for i in range(n)])
+    batch[3] = 255  # no edges: None
+    res = cv2.front_end_batch(batch, hough_threshold=40)
+    assert len(res.lines) == n
+    for i in range(n):
+        want = fr.hough_lines(fr.canny(fr.bgr2gray(batch[i]), 50, 150), 1, np.pi / 180, 40)
+        assert (res.lines[i] is None) == (want is None), i
+        if want is not None:
+            assert np.array_equal(res.lines[i], want), i
+
+
 def test_front_end_1080p_config1():
     # BASELINE config 1: one 1920x1080 class-diagram raster, seed 1000, 12 boxes
     bgr = uml_like(1000, 1080, 1920)
