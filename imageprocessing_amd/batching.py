@@ -82,7 +82,7 @@ def _run_group(images, idx, thresh_val, vert_len, horiz_len, iterations, segment
         np.stack([images[i] for i in idx], out=pin.numpy())
         dev_in = pin.to(_device._device(), non_blocking=True)
         res = pipeline.front_end_batch(dev_in, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
-                                       iterations=iterations, hough=False)
+                                       iterations=iterations, hough=False, edges=False)
         back = torch.empty((4, n, h, w), dtype=torch.uint8, pin_memory=True)
         for k, plane in enumerate((res.gray, res.thresh, res.vlines, res.hlines)):
             back[k].copy_(plane, non_blocking=True)

@@ -219,8 +219,9 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
     IPA_REQUIRE(plane_ok(C.B, (size_t)width * 3, batch), IPA_ERR_ALIGN, "front_end: bgr pointer/pitch misaligned");
     IPA_REQUIRE(plane_ok(C.G, (size_t)width, batch) && plane_ok(C.T, (size_t)width, batch) &&
                     plane_ok(C.V, (size_t)width, batch) && plane_ok(C.H, (size_t)width, batch) &&
-                    plane_ok(C.E, (size_t)width, batch),
+                    (!edges || plane_ok(C.E, (size_t)width, batch)),
                 IPA_ERR_ALIGN, "front_end: output plane pointer/pitch misaligned");
+    IPA_REQUIRE(edges || !accum, IPA_ERR_ARG, "front_end: the Hough stage needs the edges plane");
     IPA_REQUIRE(!accum || point_counts, IPA_ERR_ARG, "front_end: point_counts is NULL");
     IPA_REQUIRE(ws && ws_bytes >= chunk_ws_bytes(width, height, batch, max_points), IPA_ERR_WORKSPACE,
                 "front_end: workspace too small");
@@ -277,7 +278,7 @@ bool fused_points()
 // GaussianBlur 5x5 of the gray plane into the chunk's scratch plane (variant with blur only)
 int stage_blur(const Chunk& C, hipStream_t st)
 {
-    if (!C.blur5x5) return IPA_OK;
+    if (!C.blur5x5 || !C.E.p) return IPA_OK;
     Plane BL = mkplane(C.blur_plane, C.L.blur_pitch, C.L.blur_pitch * (size_t)C.height);
     ProfScope ps(PROF_BLUR, st);
     return launch_gauss5(C.G, BL, C.width, C.height, C.batch, C.blur_ws, C.L.blur_ws_bytes, st);
@@ -287,6 +288,7 @@ int stage_blur(const Chunk& C, hipStream_t st)
 int stage_edges(const Chunk& C, bool with_lists, hipStream_t st)
 {
     int rc;
+    if (!C.E.p) return IPA_OK;  // no edge map wanted
     const Plane csrc = C.blur5x5 ? mkplane(C.blur_plane, C.L.blur_pitch, C.L.blur_pitch * (size_t)C.height) : C.G;
     PointSink sink = {nullptr, 0, 0, nullptr};
     if (C.accum && fused_points()) {
@@ -395,7 +397,7 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
         const size_t wsc = nk > 1 ? align_up(chunk_ws_bytes(width, height, hi - lo, max_points), 256) : ws_bytes;
         int rc = chunk_init(C[c], bgr + (size_t)lo * bgr_stride, bgr_pitch, bgr_stride, gray + (size_t)lo * plane_stride,
                             thresh + (size_t)lo * plane_stride, vlines + (size_t)lo * plane_stride,
-                            hlines + (size_t)lo * plane_stride, edges + (size_t)lo * plane_stride, plane_pitch, plane_stride,
+                            hlines + (size_t)lo * plane_stride, edges ? edges + (size_t)lo * plane_stride : nullptr, plane_pitch, plane_stride,
                             accum ? accum + (size_t)lo * accum_stride : nullptr, accum_stride,
                             seg_max ? seg_max + (size_t)lo * seg_stride : nullptr, max_points,
                             point_counts ? point_counts + lo : nullptr, width, height, hi - lo, thresh_val, vert_len,

@@ -39,11 +39,12 @@ class FrontEnd:
 
     def __init__(self, batch: int, height: int, width: int, *, thresh_val: int = 128, vert_len: int = 15,
                  horiz_len: int = 15, iterations: int = 2, canny=(50, 150), blur: bool = False, hough: bool = True,
-                 max_points: int = 0):
+                 max_points: int = 0, edges: bool = True):
         L = _native.lib()
         self.batch, self.height, self.width = int(batch), int(height), int(width)
         self.thresh_val, self.vert_len, self.horiz_len = int(thresh_val), int(vert_len), int(horiz_len)
         self.iterations, self.canny, self.blur, self.hough = int(iterations), canny, bool(blur), bool(hough)
+        self.edges = bool(edges) or self.hough  # False: no Canny, the edges plane stays unwritten
         if self.vert_len < 1 or self.horiz_len < 1 or self.iterations < 1:
             raise error("front_end: vert_len, horiz_len and iterations must be >= 1")
         if max_points <= 0:
@@ -82,7 +83,8 @@ class FrontEnd:
             raise error("front_end: input batch does not match the planned shape")
         p = [self.plane(k) for k in range(5)]
         check(L.ipa_front_end_u8(
-            bgr.ptr, bgr.pitch, bgr.stride, p[0].ptr, p[1].ptr, p[2].ptr, p[3].ptr, p[4].ptr, p[0].pitch, p[0].stride,
+            bgr.ptr, bgr.pitch, bgr.stride, p[0].ptr, p[1].ptr, p[2].ptr, p[3].ptr, p[4].ptr if self.edges else None,
+            p[0].pitch, p[0].stride,
             self.accum.data_ptr() if self.hough else None, self.accum.stride(0) if self.hough else 0,
             self.seg_max.data_ptr() if self.hough else None,
             self.max_points if self.hough else 1, self.point_counts.data_ptr() if self.hough else None,
@@ -109,7 +111,7 @@ class FrontEnd:
 
 def _result(fe: FrontEnd, like, squeeze: bool, hough_threshold) -> FrontEndResult:
     to = (lambda d: d.to_tensor(squeeze)) if isinstance(like, torch.Tensor) else (lambda d: d.to_numpy(squeeze))
-    planes = [to(fe.plane(k)) for k in range(5)]
+    planes = [to(fe.plane(k)) if (k < 4 or fe.edges) else None for k in range(5)]
     acc = None
     if fe.hough:
         acc = fe.accum[0] if squeeze else fe.accum[: fe.batch]
@@ -130,11 +132,12 @@ def front_end(img, thresh_val=128, vert_len=15, horiz_len=15, iterations=2, cann
 
 
 def front_end_batch(images, thresh_val=128, vert_len=15, horiz_len=15, iterations=2, canny=(50, 150), blur=False,
-                    hough_threshold=None, hough=True) -> FrontEndResult:
-    """Full front-end of a batch uint8[N,H,W,3] in one device call."""
+                    hough_threshold=None, hough=True, edges=True) -> FrontEndResult:
+    """Full front-end of a batch uint8[N,H,W,3] in one device call.  ``edges=False`` (with ``hough=False``)
+    leaves Canny out: the parsers only use gray, thresh and the two line masks; ``edges`` is None then."""
     s = upload(images, 3, batched=True)
     fe = FrontEnd(s.batch, s.height, s.width, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
-                  iterations=iterations, canny=canny, blur=blur, hough=hough)
+                  iterations=iterations, canny=canny, blur=blur, hough=hough, edges=edges)
     fe.run(s)
     return _result(fe, images, False, hough_threshold)
 

@@ -312,11 +312,12 @@ int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t src_stride
  *   edges  = Canny(blur5x5 ? GaussianBlur(gray,(5,5),0) : gray, canny_lo, canny_hi)
  *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL;
  *            seg_max as for ipa_hough_accum_u8, may be NULL)
- * The five output planes share one pitch/stride.  Synchronises `stream` only
- * where ipa_canny_u8 does.  Batches of 64 images or more run as two halves that
- * alternate between `stream` and a helper stream of the library, and the two opens
- * run on another helper stream beside Canny; all of it is joined back into `stream`
- * before the call returns, so the caller sees ordinary stream order. */
+ * The five output planes share one pitch/stride.  edges = NULL skips Canny (the parsers
+ * only need the first four planes); accum must then be NULL as well.  Synchronises
+ * `stream` only where ipa_canny_u8 does.  Batches of 64 images or more run as chunks
+ * whose stages overlap on helper streams of the library (the vote of one chunk beside
+ * the binarisation of the next, the opens beside Canny); all of it is joined back into
+ * `stream` before the call returns, so the caller sees ordinary stream order. */
 size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points);
 int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
                      uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,

@@ -475,6 +475,19 @@ def test_front_end_batch_line_lists():
             assert np.array_equal(res.lines[i], want), i
 
 
+def test_front_end_without_canny():
+    # the parsers' prefix alone: no edges plane, no Canny work
+    batch = np.stack([uml_like(5200 + i, 90, 150) for i in range(3)])
+    res = cv2.front_end_batch(batch, thresh_val=100, hough=False, edges=False)
+    assert res.edges is None and res.accum is None
+    for i in range(3):
+        g = fr.bgr2gray(batch[i])
+        th = fr.threshold(g, 100, 255, 1)[1]
+        assert np.array_equal(res.gray[i], g) and np.array_equal(res.thresh[i], th)
+        assert np.array_equal(res.vlines[i], fr.morphology_ex(th, 2, (1, 15), 2))
+        assert np.array_equal(res.hlines[i], fr.morphology_ex(th, 2, (15, 1), 2))
+
+
 def test_front_end_1080p_config1():
     # BASELINE config 1: one 1920x1080 class-diagram raster, seed 1000, 12 boxes
     bgr = uml_like(1000, 1080, 1920)
