@@ -858,3 +858,60 @@ def test_c_abi_error_codes_streams_and_const_inputs():
     assert L.ipa_canny_u8(src.data_ptr(), pitch, h * pitch, dst.data_ptr(), pitch, h * pitch, 0, h, n, 50.0, 150.0, None, 0, sp) == 0
     assert L.ipa_canny_u8(src.data_ptr(), pitch, h * pitch, dst.data_ptr(), pitch, h * pitch, w, h, 0, 50.0, 150.0, None, 0, sp) == 0
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ randomized differential runs
+def _fuzz_image(rng, kind, h, w):
+    if kind == 0:
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == 1:
+        return ((rng.random((h, w)) < rng.uniform(0.02, 0.6)) * 255).astype(np.uint8)
+    from scipy import ndimage
+
+    return ndimage.gaussian_filter(rng.integers(0, 256, (h, w)).astype(np.float32), rng.uniform(0.8, 3.0)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_parameters_against_the_oracle(seed):
+    # random shapes and parameters, every op against the restatement (fixed seeds: reproducible)
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(1, 150)), int(rng.integers(1, 260))
+    g = _fuzz_image(rng, seed % 3, h, w)
+    binary = _fuzz_image(rng, 1, h, w)
+    # threshold: fractional, negative and saturating thresholds, odd maxval
+    for _ in range(3):
+        t, mv, typ = float(rng.uniform(-20, 280)), float(rng.uniform(0, 300)), int(rng.integers(0, 2))
+        rt, d = cv2.threshold(g, t, mv, typ)
+        ro, do = fr.threshold(g, t, mv, typ)
+        assert rt == ro and np.array_equal(d, do), (t, mv, typ)
+    # morphology: kernel sizes up to 40, even sizes, anchors, iterations, gray and binary sources
+    for src in (g, binary):
+        for _ in range(2):
+            kw_, kh_ = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+            if rng.random() < 0.5:
+                kw_, kh_ = (kw_, 1) if rng.random() < 0.5 else (1, kh_)
+            it, op = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+            k = np.ones((kh_, kw_), np.uint8)
+            got = cv2.morphologyEx(src, op, k, iterations=it)
+            assert np.array_equal(got, fr.morphology_ex(src, op, (kw_, kh_), it)), (op, kw_, kh_, it)
+    # GaussianBlur: odd sizes 1..15, sigma 0 or explicit
+    kx, ky = 2 * int(rng.integers(0, 8)) + 1, 2 * int(rng.integers(0, 8)) + 1
+    sg = 0.0 if rng.random() < 0.5 else float(rng.uniform(0.3, 4.0))
+    assert np.array_equal(cv2.GaussianBlur(g, (kx, ky), sg), fr.gaussian_blur(g, (kx, ky), sg)), (kx, ky, sg)
+    # adaptiveThreshold: blocks 3..41, both methods and types, fractional C
+    blk, cc = 2 * int(rng.integers(1, 21)) + 1, float(rng.uniform(-10, 10))
+    meth, typ = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    assert np.array_equal(cv2.adaptiveThreshold(g, 255, meth, typ, blk, cc), fr.adaptive_threshold(g, 255, meth, typ, blk, cc)), (blk, cc)
+    # Canny: arbitrary, equal and swapped thresholds
+    lo, hi = float(rng.uniform(0, 300)), float(rng.uniform(0, 300))
+    e = cv2.Canny(g, lo, hi)
+    assert np.array_equal(e, fr.canny(g, lo, hi)), (lo, hi)
+    # Hough: other resolutions
+    rho, theta = float(rng.choice([0.5, 1.0, 2.0, 3.0])), float(rng.choice([np.pi / 360, np.pi / 180, np.pi / 90, 0.05]))
+    src = e if np.count_nonzero(e) else binary
+    assert np.array_equal(cv2.hough_accumulator(src, rho, theta).cpu().numpy(), fr.hough_accum(src, rho, theta)), (rho, theta)
+    thr = int(rng.integers(1, 40))
+    a, b = cv2.HoughLines(src, rho, theta, thr), fr.hough_lines(src, rho, theta, thr)
+    assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), (rho, theta, thr)
+    _hp_same(src, rho, theta, thr, int(rng.integers(0, 30)), int(rng.integers(0, 6)))
+    _seg_same(cv2.get_segments(binary), binary)
