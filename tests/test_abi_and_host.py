@@ -178,3 +178,12 @@ def test_batching_decode_and_grouping(cd_bgr, login_bgr):
     assert groups == {cd_bgr.shape[:2]: [[0, 3], [4, 5]], login_bgr.shape[:2]: [[2]]}
     with pytest.raises(ValueError):
         ipa.group_by_shape([cd_bgr[:, :, 0]])
+
+
+def test_c_example_builds_and_links():
+    # the plain C program of examples/ compiles against include/ipamd.h and links the library
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(root, "examples", "front_end_c"))
