@@ -1,6 +1,6 @@
 // The C ABI without Python or PyTorch: one synthetic BGR image through ipa_front_end_u8, buffers from
 // hipMalloc, results checked against the CPU restatement (oracle/libfrontref.so) when it is linked in.
-// build: see examples/Makefile        run: ./front_end_c [width height]
+// build: see tests/c_abi/Makefile        run: ./front_end_c [width height]
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -10,7 +10,7 @@
 
 #include <vector>
 
-#include "../include/ipamd.h"
+#include "../../include/ipamd.h"
 
 #ifdef WITH_ORACLE
 extern "C" void fr_front_end(const uint8_t* bgr, int w, int h, int t, int line_len, int iterations, double c_lo, double c_hi,

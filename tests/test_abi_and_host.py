@@ -181,9 +181,9 @@ def test_batching_decode_and_grouping(cd_bgr, login_bgr):
 
 
 def test_c_example_builds_and_links():
-    # the plain C program of examples/ compiles against include/ipamd.h and links the library
+    # the plain C program of tests/c_abi/ compiles against include/ipamd.h and links the library
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    assert os.path.exists(os.path.join(root, "examples", "front_end_c"))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "c_abi")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(root, "tests", "c_abi", "front_end_c"))

@@ -918,13 +918,13 @@ def test_randomized_parameters_against_the_oracle(seed):
 
 
 def test_c_abi_from_a_plain_c_program():
-    # examples/front_end_c: hipMalloc + ipa_front_end_u8 + hipMemcpy, no Python or torch in the process;
+    # tests/c_abi/front_end_c: hipMalloc + ipa_front_end_u8 + hipMemcpy, no Python or torch in the process;
     # it compares all five planes and the accumulator with the CPU restatement itself
     import os
     import subprocess
 
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "front_end_c")
-    assert os.path.exists(exe), "examples/front_end_c is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi", "front_end_c")
+    assert os.path.exists(exe), "tests/c_abi/front_end_c is not built (python -c 'import __graft_entry__ as g; g.build()')"
     for args in ([], ["1001", "333"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout + r.stderr
