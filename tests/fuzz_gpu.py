@@ -1,0 +1,113 @@
+"""Randomised fused-front-end cases against the CPU restatement (test infrastructure, not collected by
+pytest): python tests/fuzz_gpu.py [cases] [first seed].  Shapes are biased towards the tile, strip and
+word boundaries of the kernels (multiples of 32 / 64 / 128 / 248 / 256 +-1), batches towards the sizes
+at which the fused pass switches schedules (1, 63, 64, 65, 128+), parameters over the ranges the
+parsers use and beyond.  Prints one line per failing case and a summary; exit status 1 on any failure."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import imageprocessing_amd as ipa  # noqa: E402
+from oracle import frontref as fr  # noqa: E402
+
+EDGES = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 29, 31, 32, 33, 63, 64, 65, 127, 128, 129, 247, 248, 249, 255, 256, 257,
+         495, 496, 497, 511, 512, 513, 743, 744, 745, 1023, 1024, 1025]
+
+
+def pick_dim(rng, hi):
+    if rng.random() < 0.6:
+        v = int(rng.choice(EDGES)) + int(rng.integers(-1, 2)) * int(rng.random() < 0.3)
+    else:
+        v = int(rng.integers(1, hi))
+    return max(1, min(v, hi))
+
+
+def diagram(rng, n, h, w):
+    """White pages with dark strokes, boxes, speckle and, sometimes, a gradient or noise."""
+    img = np.full((n, h, w, 3), 255, np.uint8)
+    for b in range(n):
+        kind = rng.integers(0, 4)
+        if kind == 3:
+            img[b] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            continue
+        for _ in range(int(rng.integers(0, 12))):
+            x0, x1 = sorted(int(v) for v in rng.integers(0, w + 1, 2))
+            y0, y1 = sorted(int(v) for v in rng.integers(0, h + 1, 2))
+            t = int(rng.integers(1, 6))
+            col = rng.integers(0, 120, 3).astype(np.uint8)
+            img[b, y0:y0 + t, x0:x1] = col
+            img[b, max(y1 - t, 0):y1, x0:x1] = col
+            img[b, y0:y1, x0:x0 + t] = col
+            img[b, y0:y1, max(x1 - t, 0):x1] = col
+        if kind >= 1:
+            m = rng.random((h, w)) < 0.02
+            img[b][m] = rng.integers(0, 256, (int(m.sum()), 3), dtype=np.uint8)
+        if kind == 2:
+            ramp = (np.arange(w)[None, :] * 90 // max(w, 1)).astype(np.int16)
+            img[b] = np.clip(img[b].astype(np.int16) - ramp[:, :, None], 0, 255).astype(np.uint8)
+    return img
+
+
+def oracle_case(bgr, t, vl, hl, it, lo, hi, blur, hough, edges):
+    g = fr.bgr2gray(bgr)
+    _, th = fr.threshold(g, t, 255, 1)
+    v = fr.morphology_ex(th, 2, (1, vl), it)
+    hz = fr.morphology_ex(th, 2, (hl, 1), it)
+    e = acc = None
+    if edges:
+        src = fr.gaussian_blur(g, (5, 5), 0) if blur else g
+        e = fr.canny(src, lo, hi)
+        if hough:
+            acc = fr.hough_accum(e, 1.0, np.pi / 180)
+    return g, th, v, hz, e, acc
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    t_start = time.time()
+    for c in range(cases):
+        rng = np.random.default_rng(77000 + seed0 + c)
+        w, h = pick_dim(rng, 1100), pick_dim(rng, 700)
+        n = int(rng.choice([1, 1, 2, 3, 5, 63, 64, 65, 70, 96, 128, 131]))
+        while n > 1 and n * w * h > 24_000_000:
+            n = max(1, n // 2)
+        t = int(rng.integers(0, 256))
+        vl, hl, it = int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 4))
+        lo, hi = float(rng.uniform(0, 300)), float(rng.uniform(0, 400))
+        blur, hough = bool(rng.random() < 0.3), bool(rng.random() < 0.7)
+        edges = hough or bool(rng.random() < 0.7)
+        imgs = diagram(rng, n, h, w)
+        tag = f"case {seed0 + c}: n={n} {w}x{h} t={t} v={vl} h={hl} it={it} canny=({lo:.1f},{hi:.1f}) blur={blur} hough={hough} edges={edges}"
+        try:
+            r = ipa.front_end_batch(imgs, thresh_val=t, vert_len=vl, horiz_len=hl, iterations=it, canny=(lo, hi),
+                                    blur=blur, hough=hough, edges=edges)
+            acc = r.accum.cpu().numpy() if r.accum is not None else None
+            check = sorted(set([0, n - 1, int(rng.integers(0, n)), int(rng.integers(0, n))]))
+            for b in check:
+                exp = oracle_case(imgs[b], t, vl, hl, it, lo, hi, blur, hough, edges)
+                got = (r.gray[b], r.thresh[b], r.vlines[b], r.hlines[b], r.edges[b] if edges else None,
+                       acc[b] if acc is not None else None)
+                for name, a, e in zip(("gray", "thresh", "vlines", "hlines", "edges", "accum"), got, exp):
+                    if e is None:
+                        continue
+                    if not np.array_equal(np.asarray(a), e):
+                        bad += 1
+                        print(f"FAIL {tag} image {b} plane {name}: {int((np.asarray(a) != e).sum())} cells differ", flush=True)
+                        break
+        except Exception as ex:  # a raised error is a failure of the case, the run goes on
+            bad += 1
+            print(f"ERROR {tag}: {type(ex).__name__}: {ex}", flush=True)
+        if (c + 1) % 25 == 0:
+            print(f"{c + 1} cases, {bad} bad, {time.time() - t_start:.0f} s", flush=True)
+    print(f"fuzz: {cases} cases from seed {seed0}, {bad} bad")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
