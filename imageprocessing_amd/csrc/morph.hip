@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bit
             v.a1 = (v.a1 & m.a1) | (ident & ~m.a1);
             v.a2 = (v.a2 & m.a2) | (ident & ~m.a2);
 #pragma unroll
-            for (int mm = 1; mm < 32; mm <<= 1)
-                if (mm < px) v = comb3(v, look_right(v, mm, ident), dil);
+            for (int mm = 1; mm <= 32; mm <<= 1)  // px = 64 (kx = 64, 65) needs the whole-word step too
+                if (mm < px) v = comb3(v, look(v, mm, ident), dil);
             v = comb3(look(v, -ax, ident), look(v, kx - px - ax, ident), dil);
             dil = !dil;
         }

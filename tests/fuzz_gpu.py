@@ -1,5 +1,6 @@
 """Randomised fused-front-end cases against the CPU restatement (test infrastructure, not collected by
-pytest): python tests/fuzz_gpu.py [cases] [first seed].  Shapes are biased towards the tile, strip and
+pytest): python tests/fuzz_gpu.py [cases] [first seed] for the fused pass, python tests/fuzz_gpu.py ops
+[cases] [first seed] for every single operation.  Shapes are biased towards the tile, strip and
 word boundaries of the kernels (multiples of 32 / 64 / 128 / 248 / 256 +-1), batches towards the sizes
 at which the fused pass switches schedules (1, 63, 64, 65, 128+), parameters over the ranges the
 parsers use and beyond.  Prints one line per failing case and a summary; exit status 1 on any failure."""
@@ -66,7 +67,103 @@ def oracle_case(bgr, t, vl, hl, it, lo, hi, blur, hough, edges):
     return g, th, v, hz, e, acc
 
 
+def gray_image(rng, kind, h, w):
+    if kind == 0:
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == 1:
+        return ((rng.random((h, w)) < rng.uniform(0.02, 0.6)) * 255).astype(np.uint8)
+    if kind == 2:
+        return fr.bgr2gray(diagram(rng, 1, h, w)[0])
+    from scipy import ndimage
+
+    return ndimage.gaussian_filter(rng.integers(0, 256, (h, w)).astype(np.float32), rng.uniform(0.8, 3.0)).astype(np.uint8)
+
+
+def ops_case(rng):
+    """Every single operation of the cv2-style module on one random image; returns the name of the
+    first operation whose result differs from the restatement, or None."""
+    cv2 = ipa
+    w, h = pick_dim(rng, 1100), pick_dim(rng, 700)
+    g = gray_image(rng, int(rng.integers(0, 4)), h, w)
+    binary = gray_image(rng, int(rng.choice([1, 2])), h, w)
+    if binary.max() > 0 and len(np.unique(binary)) > 2:
+        binary = fr.threshold(binary, 128, 255, 1)[1]
+    bgr = diagram(rng, 1, h, w)[0]
+    if not np.array_equal(cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY), fr.bgr2gray(bgr)):
+        return f"cvtColor {w}x{h}"
+    t, mv, typ = float(rng.uniform(-20, 280)), float(rng.uniform(0, 300)), int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        typ |= cv2.THRESH_OTSU
+    rt, d = cv2.threshold(g, t, mv, typ)
+    ro, do = fr.threshold(g, t, mv, typ)
+    if rt != ro or not np.array_equal(d, do):
+        return f"threshold {w}x{h} {t} {mv} {typ}"
+    for src in (g, binary):
+        kw_, kh_ = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        r = rng.random()
+        if r < 0.6:
+            kw_, kh_ = (kw_, 1) if rng.random() < 0.5 else (1, kh_)
+        elif r < 0.8:
+            kw_, kh_ = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        it, op = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+        got = cv2.morphologyEx(src, op, np.ones((kh_, kw_), np.uint8), iterations=it)
+        if not np.array_equal(got, fr.morphology_ex(src, op, (kw_, kh_), it)):
+            return f"morphologyEx {w}x{h} op={op} k=({kw_},{kh_}) it={it} binary={src is binary}"
+    kx, ky = 2 * int(rng.integers(0, 8)) + 1, 2 * int(rng.integers(0, 8)) + 1
+    sg = 0.0 if rng.random() < 0.5 else float(rng.uniform(0.3, 4.0))
+    if not np.array_equal(cv2.GaussianBlur(g, (kx, ky), sg), fr.gaussian_blur(g, (kx, ky), sg)):
+        return f"GaussianBlur {w}x{h} ({kx},{ky}) {sg}"
+    blk, cc = 2 * int(rng.integers(1, 21)) + 1, float(rng.uniform(-10, 10))
+    meth, typ = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    if not np.array_equal(cv2.adaptiveThreshold(g, 255, meth, typ, blk, cc), fr.adaptive_threshold(g, 255, meth, typ, blk, cc)):
+        return f"adaptiveThreshold {w}x{h} {meth} {typ} {blk} {cc}"
+    lo, hi = float(rng.uniform(0, 300)), float(rng.uniform(0, 300))
+    e = cv2.Canny(g, lo, hi)
+    if not np.array_equal(e, fr.canny(g, lo, hi)):
+        return f"Canny {w}x{h} {lo} {hi}"
+    rho, theta = float(rng.choice([0.5, 1.0, 2.0, 3.0])), float(rng.choice([np.pi / 360, np.pi / 180, np.pi / 90, 0.05]))
+    src = e if np.count_nonzero(e) else binary
+    if not np.array_equal(cv2.hough_accumulator(src, rho, theta).cpu().numpy(), fr.hough_accum(src, rho, theta)):
+        return f"hough_accumulator {w}x{h} {rho} {theta}"
+    thr = int(rng.integers(1, 120))
+    a, b = cv2.HoughLines(src, rho, theta, thr), fr.hough_lines(src, rho, theta, thr)
+    if (a is None) != (b is None) or (a is not None and not np.array_equal(a, b)):
+        return f"HoughLines {w}x{h} {rho} {theta} {thr}"
+    if np.count_nonzero(src) < 60000:  # the restatement visits pixel by pixel
+        thr, mll, gap = int(rng.integers(5, 120)), int(rng.integers(0, 60)), int(rng.integers(0, 12))
+        a, b = cv2.HoughLinesP(src, rho, theta, thr, minLineLength=mll, maxLineGap=gap), fr.hough_lines_p(src, rho, theta, thr, mll, gap)
+        a = np.zeros((0, 4), np.int32) if a is None else np.asarray(a).reshape(-1, 4)
+        b = np.zeros((0, 4), np.int32) if b is None else np.asarray(b).reshape(-1, 4)
+        if not np.array_equal(a, b):
+            return f"HoughLinesP {w}x{h} {rho} {theta} {thr} {mll} {gap}"
+    got = np.asarray(cv2.get_segments(binary)).reshape(-1, 4)
+    exp = np.asarray(fr.external_boxes(binary)).reshape(-1, 4)
+    if not np.array_equal(got, exp):
+        return f"get_segments {w}x{h}"
+    return None
+
+
+def main_ops(cases, seed0):
+    bad = 0
+    t_start = time.time()
+    for c in range(cases):
+        rng = np.random.default_rng(99000 + seed0 + c)
+        try:
+            what = ops_case(rng)
+        except Exception as ex:
+            what = f"{type(ex).__name__}: {ex}"
+        if what:
+            bad += 1
+            print(f"FAIL ops case {seed0 + c}: {what}", flush=True)
+        if (c + 1) % 25 == 0:
+            print(f"{c + 1} cases, {bad} bad, {time.time() - t_start:.0f} s", flush=True)
+    print(f"fuzz ops: {cases} cases from seed {seed0}, {bad} bad")
+    return 1 if bad else 0
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ops":
+        return main_ops(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0

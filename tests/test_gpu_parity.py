@@ -917,6 +917,21 @@ def test_randomized_parameters_against_the_oracle(seed):
     _seg_same(cv2.get_segments(binary), binary)
 
 
+@pytest.mark.parametrize("kx", [31, 32, 33, 63, 64, 65, 66])
+def test_binary_horizontal_lines_up_to_two_words(kx):
+    # one erode / dilate with a horizontal line whose reach is a whole 32-pixel word to each side
+    # (64 and 65 wide: the widest the register kernel takes; 33 with two iterations folds to 65)
+    rng = np.random.default_rng(kx)
+    for w, h in ((264, 40), (64, 9), (1, 7), (911, 12)):
+        m = ((rng.random((h, w)) < 0.7) * 255).astype(np.uint8)
+        for op in (cv2.MORPH_ERODE, cv2.MORPH_DILATE, cv2.MORPH_OPEN, cv2.MORPH_CLOSE):
+            got = cv2.morphologyEx(m, op, np.ones((1, kx), np.uint8))
+            assert np.array_equal(got, fr.morphology_ex(m, op, (kx, 1), 1)), (kx, w, h, op)
+    m = ((rng.random((30, 300)) < 0.8) * 255).astype(np.uint8)
+    assert np.array_equal(cv2.dilate(m, np.ones((1, 33), np.uint8), iterations=2), fr.morphology_ex(m, 1, (33, 1), 2))
+    assert np.array_equal(cv2.erode(m, np.ones((1, 33), np.uint8), iterations=2), fr.morphology_ex(m, 0, (33, 1), 2))
+
+
 def test_c_abi_from_a_plain_c_program():
     # tests/c_abi/front_end_c: hipMalloc + ipa_front_end_u8 + hipMemcpy, no Python or torch in the process;
     # it compares all five planes and the accumulator with the CPU restatement itself
