@@ -111,7 +111,13 @@ def upload(arr, channels: int, *, batched: bool = False) -> DevImage:
         return img
     img = DevImage.empty(batch, height, width, channels)
     if batch * height * rb:
-        host = torch.from_numpy(np.ascontiguousarray(arr).reshape(batch, height, rb)) if not is_torch else arr.contiguous().reshape(batch, height, rb)
+        if is_torch:
+            host = arr.contiguous().reshape(batch, height, rb)
+        else:
+            a = np.ascontiguousarray(arr)
+            if any(st < 0 for st in a.strides):  # a reversed axis of length 1 still counts as contiguous
+                a = a.copy()
+            host = torch.from_numpy(a.reshape(batch, height, rb))
         img.valid().copy_(host)
     return img
 

@@ -45,7 +45,8 @@ def gather_to_rank0(local: np.ndarray, n_items: int, rank: int, world_size: int,
 
     if world_size == 1:
         return local
-    t = torch.from_numpy(np.ascontiguousarray(local))
+    t = torch.from_numpy(np.array(local, order="C", copy=True) if any(st < 0 for st in np.asarray(local).strides)
+                         else np.ascontiguousarray(local))
     shapes = [(shard_range(n_items, r, world_size)[1] - shard_range(n_items, r, world_size)[0],) + tuple(local.shape[1:])
               for r in range(world_size)]
     if rank == 0:

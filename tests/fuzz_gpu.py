@@ -1,6 +1,7 @@
 """Randomised fused-front-end cases against the CPU restatement (test infrastructure, not collected by
 pytest): python tests/fuzz_gpu.py [cases] [first seed] for the fused pass, python tests/fuzz_gpu.py ops
-[cases] [first seed] for every single operation.  Shapes are biased towards the tile, strip and
+[cases] [first seed] for every single operation, python tests/fuzz_gpu.py batch [cases] [first seed] for
+the batched helpers, strided / device inputs, rectangle erase and large shapes.  Shapes are biased towards the tile, strip and
 word boundaries of the kernels (multiples of 32 / 64 / 128 / 248 / 256 +-1), batches towards the sizes
 at which the fused pass switches schedules (1, 63, 64, 65, 128+), parameters over the ranges the
 parsers use and beyond.  Prints one line per failing case and a summary; exit status 1 on any failure."""
@@ -105,6 +106,9 @@ def ops_case(rng):
             kw_, kh_ = (kw_, 1) if rng.random() < 0.5 else (1, kh_)
         elif r < 0.8:
             kw_, kh_ = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        if rng.random() < 0.15:  # long lines (the whiteboard configuration uses 101 and 201)
+            long = int(rng.choice([95, 96, 97, 101, 127, 128, 129, 201, 255, 256, 257, 300]))
+            kw_, kh_ = (long, 1) if rng.random() < 0.5 else (1, long)
         it, op = int(rng.integers(1, 4)), int(rng.integers(0, 4))
         got = cv2.morphologyEx(src, op, np.ones((kh_, kw_), np.uint8), iterations=it)
         if not np.array_equal(got, fr.morphology_ex(src, op, (kw_, kh_), it)):
@@ -143,27 +147,99 @@ def ops_case(rng):
     return None
 
 
-def main_ops(cases, seed0):
+def batch_case(rng):
+    """Batched helpers, strided and device-tensor inputs, rectangle erase + re-binarisation, and now and
+    then a large shape; returns a description of the first difference or None."""
+    import torch
+
+    cv2 = ipa
+    big = rng.random() < 0.04
+    w, h = (pick_dim(rng, 5000), pick_dim(rng, 3000)) if big else (pick_dim(rng, 600), pick_dim(rng, 400))
+    n = 1 if big else int(rng.choice([1, 2, 3, 7, 33, 70]))
+    while n > 1 and n * w * h > 6_000_000:
+        n = max(1, n // 2)
+    masks = np.stack([gray_image(rng, int(rng.choice([1, 2])), h, w) for _ in range(n)])
+    masks = np.where(masks > 127, 0, 255).astype(np.uint8) if rng.random() < 0.5 else ((masks > 0) * 255).astype(np.uint8)
+    # segments of a batch, from numpy and from a device tensor
+    src = masks if rng.random() < 0.5 else torch.from_numpy(masks).cuda()
+    got = ipa.segments_batch(src)
+    for b in range(n):
+        exp = fr.external_boxes(masks[b])
+        if not np.array_equal(np.asarray(got[b], dtype=np.int64).reshape(-1, 4), exp):
+            return f"segments_batch n={n} {w}x{h} image {b}"
+    # strided view as input (cv2 accepts any strides)
+    wide = np.zeros((h, w + 7), np.uint8)
+    wide[:, 3:3 + w] = masks[0]
+    view = wide[:, 3:3 + w]
+    k = int(rng.integers(1, 40))
+    if not np.array_equal(cv2.erode(view, np.ones((1, k), np.uint8)), fr.morphology_ex(masks[0], 0, (k, 1), 1)):
+        return f"erode on a strided view {w}x{h} k={k}"
+    rev = masks[0][::-1]
+    if not np.array_equal(cv2.dilate(rev, np.ones((k, 1), np.uint8)), fr.morphology_ex(np.ascontiguousarray(rev), 1, (1, k), 1)):
+        return f"dilate on a flipped view {w}x{h} k={k}"
+    # edge maps: batched HoughLinesP and batched peaks
+    e = np.stack([fr.canny(gray_image(rng, 2, h, w), 50, 150) for _ in range(min(n, 4))])
+    if np.count_nonzero(e) < 40000 * len(e):
+        thr, mll, gap = int(rng.integers(10, 100)), int(rng.integers(0, 50)), int(rng.integers(0, 10))
+        got = ipa.hough_lines_p_batch(e, 1.0, np.pi / 180, thr, minLineLength=mll, maxLineGap=gap)
+        for b in range(len(e)):
+            exp = fr.hough_lines_p(e[b], 1.0, np.pi / 180, thr, mll, gap)
+            a = np.zeros((0, 4), np.int32) if got[b] is None else np.asarray(got[b]).reshape(-1, 4)
+            x = np.zeros((0, 4), np.int32) if exp is None else exp.reshape(-1, 4)
+            if not np.array_equal(a, x):
+                return f"hough_lines_p_batch {w}x{h} image {b} thr={thr} len={mll} gap={gap}"
+    # rectangle erase + second binarisation
+    bgr = diagram(rng, n, h, w)
+    rects = []
+    for _ in range(int(rng.integers(0, 9))):
+        x1, x2 = sorted(int(v) for v in rng.integers(-20, w + 20, 2))
+        y1, y2 = sorted(int(v) for v in rng.integers(-20, h + 20, 2))
+        rects.append((int(rng.integers(0, n)), max(x1, 0), max(y1, 0), max(x2, 0), max(y2, 0)))
+    t = int(rng.integers(0, 256))
+    col = tuple(int(v) for v in rng.integers(0, 256, 3))
+    eb, g, th = ipa.rebinarize(bgr, rects, thresh_val=t, bg_color=col)
+    ref = bgr.copy()
+    for (b, x1, y1, x2, y2) in rects:
+        ref[b, y1:y2, x1:x2] = col
+    if not np.array_equal(eb, ref):
+        return f"rebinarize (erase) n={n} {w}x{h}"
+    for b in sorted(set([0, n - 1])):
+        gg = fr.bgr2gray(ref[b])
+        if not np.array_equal(g[b], gg) or not np.array_equal(th[b], fr.threshold(gg, t, 255, 1)[1]):
+            return f"rebinarize (gray/threshold) n={n} {w}x{h} image {b}"
+    # one large or odd-shaped full front-end with the line list
+    r = ipa.front_end(bgr[0], thresh_val=t, hough_threshold=int(rng.integers(20, 300)))
+    exp = oracle_case(bgr[0], t, 15, 15, 2, 50, 150, False, True, True)
+    for name, a, x in zip(("gray", "thresh", "vlines", "hlines", "edges"), (r.gray, r.thresh, r.vlines, r.hlines, r.edges), exp):
+        if not np.array_equal(a, x):
+            return f"front_end {w}x{h} plane {name}"
+    if not np.array_equal(r.accum.cpu().numpy(), exp[5]):
+        return f"front_end {w}x{h} accum"
+    return None
+
+
+def main_ops(cases, seed0, case=ops_case, base=99000, name="ops"):
     bad = 0
     t_start = time.time()
     for c in range(cases):
-        rng = np.random.default_rng(99000 + seed0 + c)
+        rng = np.random.default_rng(base + seed0 + c)
         try:
-            what = ops_case(rng)
+            what = case(rng)
         except Exception as ex:
             what = f"{type(ex).__name__}: {ex}"
         if what:
             bad += 1
-            print(f"FAIL ops case {seed0 + c}: {what}", flush=True)
+            print(f"FAIL {name} case {seed0 + c}: {what}", flush=True)
         if (c + 1) % 25 == 0:
             print(f"{c + 1} cases, {bad} bad, {time.time() - t_start:.0f} s", flush=True)
-    print(f"fuzz ops: {cases} cases from seed {seed0}, {bad} bad")
+    print(f"fuzz {name}: {cases} cases from seed {seed0}, {bad} bad")
     return 1 if bad else 0
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "ops":
-        return main_ops(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("ops", "batch"):
+        n, s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 0
+        return main_ops(n, s0) if sys.argv[1] == "ops" else main_ops(n, s0, batch_case, 55000, "batch")
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0

@@ -932,6 +932,20 @@ def test_binary_horizontal_lines_up_to_two_words(kx):
     assert np.array_equal(cv2.erode(m, np.ones((1, 33), np.uint8), iterations=2), fr.morphology_ex(m, 0, (33, 1), 2))
 
 
+def test_reversed_and_strided_numpy_views():
+    # cv2 takes any numpy view (it copies what is not contiguous): flipped rows / columns / channels,
+    # also of a single row or column, whose reversed view numpy still flags as contiguous
+    rng = np.random.default_rng(5)
+    for h, w in ((37, 53), (1, 40), (29, 1), (1, 1)):
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for view in (bgr[::-1], bgr[:, ::-1], bgr[:, :, ::-1], bgr[::-1, ::-1, ::-1]):
+            assert np.array_equal(cv2.cvtColor(view, cv2.COLOR_BGR2GRAY), fr.bgr2gray(np.ascontiguousarray(view).copy()))
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for view in (g[::-1], g[:, ::-1], g[::-1, ::-1], np.asfortranarray(g)):
+            want = fr.threshold(np.array(view, order="C", copy=True), 100, 255, 1)[1]
+            assert np.array_equal(cv2.threshold(view, 100, 255, cv2.THRESH_BINARY_INV)[1], want)
+
+
 def test_c_abi_from_a_plain_c_program():
     # tests/c_abi/front_end_c: hipMalloc + ipa_front_end_u8 + hipMemcpy, no Python or torch in the process;
     # it compares all five planes and the accumulator with the CPU restatement itself
