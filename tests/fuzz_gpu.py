@@ -1,7 +1,8 @@
 """Randomised fused-front-end cases against the CPU restatement (test infrastructure, not collected by
 pytest): python tests/fuzz_gpu.py [cases] [first seed] for the fused pass, python tests/fuzz_gpu.py ops
 [cases] [first seed] for every single operation, python tests/fuzz_gpu.py batch [cases] [first seed] for
-the batched helpers, strided / device inputs, rectangle erase and large shapes.  Shapes are biased towards the tile, strip and
+the batched helpers, strided / device inputs, rectangle erase and large shapes, python tests/fuzz_gpu.py abi
+[cases] [first seed] for the C entry points with minimal (16-byte) pitches, strides and base alignment.  Shapes are biased towards the tile, strip and
 word boundaries of the kernels (multiples of 32 / 64 / 128 / 248 / 256 +-1), batches towards the sizes
 at which the fused pass switches schedules (1, 63, 64, 65, 128+), parameters over the ranges the
 parsers use and beyond.  Prints one line per failing case and a summary; exit status 1 on any failure."""
@@ -218,6 +219,167 @@ def batch_case(rng):
     return None
 
 
+class Dev:
+    """A batch of rows in device memory with a caller-chosen layout: base pointer 16-byte aligned but
+    not more, pitch and stride any multiples of 16, the gaps filled with a marker."""
+
+    def __init__(self, rng, n, h, rb, data=None):
+        import torch
+
+        self.n, self.h, self.rb = n, h, rb
+        self.pitch = ((rb + 15) // 16 + int(rng.integers(0, 4)) * int(rng.random() < 0.6)) * 16
+        self.pitch = max(self.pitch, 16)
+        self.stride = self.pitch * h + 16 * int(rng.integers(0, 5)) * int(rng.random() < 0.5)
+        self.off = 16 * int(rng.integers(0, 16))
+        self.t = torch.full((self.off + max(n, 1) * self.stride + 4096,), 0xAB, dtype=torch.uint8, device="cuda")
+        if data is not None and n * h * rb:
+            self.view().copy_(torch.from_numpy(np.ascontiguousarray(data).reshape(n, h, rb)).cuda())
+
+    def view(self):
+        import torch
+
+        return torch.as_strided(self.t, (self.n, self.h, self.rb), (self.stride, self.pitch, 1), self.off)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.off
+
+    def get(self):
+        return self.view().cpu().numpy()
+
+
+def abi_case(rng):
+    """The C entry points called directly with pitches, strides and base pointers that only meet the
+    documented 16-byte rule."""
+    import torch
+
+    from imageprocessing_amd import _native
+
+    L = _native.lib()
+    w, h = pick_dim(rng, 700), pick_dim(rng, 400)
+    n = int(rng.choice([1, 1, 2, 3, 5, 66]))
+    while n > 1 and n * w * h > 4_000_000:
+        n = max(1, n // 2)
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def ws_for(nbytes):
+        return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device="cuda")
+
+    def ok(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: rc={rc} {_native.last_error()}")
+
+    bgr = diagram(rng, n, h, w)
+    gray = np.stack([fr.bgr2gray(bgr[b]) for b in range(n)])
+    S = Dev(rng, n, h, 3 * w, bgr)
+    # bgr2gray
+    G = Dev(rng, n, h, w)
+    ok(L.ipa_bgr2gray_u8(S.ptr, S.pitch, S.stride, G.ptr, G.pitch, G.stride, w, h, n, sp), "bgr2gray")
+    if not np.array_equal(G.get(), gray):
+        return f"ipa_bgr2gray_u8 n={n} {w}x{h} pitches {S.pitch}/{G.pitch}"
+    # gray + threshold in one pass
+    t = float(rng.integers(0, 256))
+    G2, T2 = Dev(rng, n, h, w), None
+    T2 = Dev(rng, n, h, w)
+    T2.pitch, T2.stride = G2.pitch, G2.stride
+    T2.t = torch.full_like(G2.t, 0xAB)
+    T2.off = G2.off
+    ok(L.ipa_gray_threshold_u8(S.ptr, S.pitch, S.stride, G2.ptr, T2.ptr, G2.pitch, G2.stride, w, h, n, t, 255.0, 1, sp), "gray_threshold")
+    th = np.stack([fr.threshold(gray[b], t, 255, 1)[1] for b in range(n)])
+    if not np.array_equal(G2.get(), gray) or not np.array_equal(T2.get(), th):
+        return f"ipa_gray_threshold_u8 n={n} {w}x{h}"
+    # threshold
+    D = Dev(rng, n, h, w)
+    typ = int(rng.integers(0, 2))
+    ok(L.ipa_threshold_u8(G.ptr, G.pitch, G.stride, D.ptr, D.pitch, D.stride, w, h, n, t, 200.0, typ, sp), "threshold")
+    if not np.array_equal(D.get(), np.stack([fr.threshold(gray[b], t, 200, typ)[1] for b in range(n)])):
+        return f"ipa_threshold_u8 n={n} {w}x{h}"
+    # morphology, binary and 8-bit
+    TH = Dev(rng, n, h, w, th)
+    for src, arr, binary in ((TH, th, 1), (G, gray, 0)):
+        kw_, kh_ = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        if rng.random() < 0.6:
+            kw_, kh_ = (kw_, 1) if rng.random() < 0.5 else (1, kh_)
+        it, op = int(rng.integers(1, 3)), int(rng.integers(0, 4))
+        ws = ws_for(L.ipa_morph_workspace_bytes(w, h, n))
+        D = Dev(rng, n, h, w)
+        ok(L.ipa_morph_u8(src.ptr, src.pitch, src.stride, D.ptr, D.pitch, D.stride, w, h, n, op, kw_, kh_, -1, -1, it, binary,
+                          ws.data_ptr(), ws.numel(), sp), "morph")
+        if not np.array_equal(D.get(), np.stack([fr.morphology_ex(arr[b], op, (kw_, kh_), it) for b in range(n)])):
+            return f"ipa_morph_u8 n={n} {w}x{h} op={op} k=({kw_},{kh_}) it={it} binary={binary} pitches {src.pitch}/{D.pitch}"
+    # GaussianBlur
+    kx, ky = 2 * int(rng.integers(0, 6)) + 1, 2 * int(rng.integers(0, 6)) + 1
+    ws = ws_for(L.ipa_gaussian_blur_workspace_bytes(w, h, n))
+    D = Dev(rng, n, h, w)
+    ok(L.ipa_gaussian_blur_u8(G.ptr, G.pitch, G.stride, D.ptr, D.pitch, D.stride, w, h, n, kx, ky, 0.0, 0.0, 4, ws.data_ptr(), ws.numel(), sp), "blur")
+    if not np.array_equal(D.get(), np.stack([fr.gaussian_blur(gray[b], (kx, ky), 0) for b in range(n)])):
+        return f"ipa_gaussian_blur_u8 n={n} {w}x{h} ({kx},{ky})"
+    # adaptive threshold
+    blk = 2 * int(rng.integers(1, 16)) + 1
+    ws = ws_for(L.ipa_adaptive_threshold_workspace_bytes(w, h, n))
+    D = Dev(rng, n, h, w)
+    meth = int(rng.integers(0, 2))
+    ok(L.ipa_adaptive_threshold_u8(G.ptr, G.pitch, G.stride, D.ptr, D.pitch, D.stride, w, h, n, 255.0, meth, 0, blk, 2.0, ws.data_ptr(), ws.numel(), sp), "adaptive")
+    if not np.array_equal(D.get(), np.stack([fr.adaptive_threshold(gray[b], 255, meth, 0, blk, 2.0) for b in range(n)])):
+        return f"ipa_adaptive_threshold_u8 n={n} {w}x{h} {meth} {blk}"
+    # Canny
+    lo, hi = float(rng.uniform(0, 200)), float(rng.uniform(0, 300))
+    ws = ws_for(L.ipa_canny_workspace_bytes(w, h, n))
+    E = Dev(rng, n, h, w)
+    ok(L.ipa_canny_u8(G.ptr, G.pitch, G.stride, E.ptr, E.pitch, E.stride, w, h, n, lo, hi, ws.data_ptr(), ws.numel(), sp), "canny")
+    edges = np.stack([fr.canny(gray[b], lo, hi) for b in range(n)])
+    if not np.array_equal(E.get(), edges):
+        return f"ipa_canny_u8 n={n} {w}x{h} pitches {G.pitch}/{E.pitch}"
+    # Hough accumulator
+    na, nr = fr.hough_dims(w, h, 1.0, np.pi / 180)
+    cells = (na + 2) * (nr + 2)
+    astride = cells + int(rng.integers(0, 3)) * 4
+    acc = torch.full((n * astride + 16,), -7, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ws = ws_for(L.ipa_hough_workspace_bytes(w, h, n, 0))
+    ok(L.ipa_hough_accum_u8(E.ptr, E.pitch, E.stride, w, h, n, 1.0, np.pi / 180, acc.data_ptr(), astride, None, 0, cnt.data_ptr(),
+                            ws.data_ptr(), ws.numel(), sp), "hough")
+    a = acc.cpu().numpy()
+    for b in range(n):
+        if not np.array_equal(a[b * astride : b * astride + cells].reshape(na + 2, nr + 2), fr.hough_accum(edges[b], 1.0, np.pi / 180)):
+            return f"ipa_hough_accum_u8 n={n} {w}x{h} image {b}"
+    # segments
+    ws = ws_for(L.ipa_segments_workspace_bytes(w, h, n, w * h))
+    boxes = torch.zeros((n, 4096, 4), dtype=torch.int32, device="cuda")
+    ok(L.ipa_segments_u8(TH.ptr, TH.pitch, TH.stride, w, h, n, w * h, boxes.data_ptr(), 4096, cnt.data_ptr(), ws.data_ptr(), ws.numel(), sp), "segments")
+    c, bx = cnt.cpu().numpy(), boxes.cpu().numpy()
+    for b in range(n):
+        exp = fr.external_boxes(th[b])
+        if c[b] != len(exp) or (c[b] <= 4096 and not np.array_equal(bx[b, : c[b]], exp)):
+            return f"ipa_segments_u8 n={n} {w}x{h} image {b}"
+    # fused pass, five planes of one layout
+    P = [Dev(rng, n, h, w) for _ in range(5)]
+    for q in P[1:]:
+        q.pitch, q.stride, q.off = P[0].pitch, P[0].stride, P[0].off
+        q.t = torch.full_like(P[0].t, 0xAB)
+    hough = rng.random() < 0.7
+    tv = int(rng.integers(0, 256))
+    ws = ws_for(L.ipa_front_end_workspace_bytes(w, h, n, 0 if hough else 1))
+    acc.fill_(-7)
+    ok(L.ipa_front_end_u8(S.ptr, S.pitch, S.stride, P[0].ptr, P[1].ptr, P[2].ptr, P[3].ptr, P[4].ptr, P[0].pitch, P[0].stride,
+                          acc.data_ptr() if hough else None, astride, None, 0 if hough else 1, cnt.data_ptr(), w, h, n, tv, 15, 15, 2,
+                          lo, hi, 0, ws.data_ptr(), ws.numel(), sp), "front_end")
+    a = acc.cpu().numpy()
+    for b in sorted(set([0, n - 1])):
+        exp = oracle_case(bgr[b], tv, 15, 15, 2, lo, hi, False, hough, True)
+        for k, name in enumerate(("gray", "thresh", "vlines", "hlines", "edges")):
+            if not np.array_equal(P[k].get()[b], exp[k]):
+                return f"ipa_front_end_u8 n={n} {w}x{h} image {b} plane {name} pitch {P[0].pitch} stride {P[0].stride}"
+        if hough and not np.array_equal(a[b * astride : b * astride + cells].reshape(na + 2, nr + 2), exp[5]):
+            return f"ipa_front_end_u8 n={n} {w}x{h} image {b} accum"
+    # nothing outside the images' rows may change except row tails up to the pitch
+    for d in (G, E, P[0]):
+        flat = d.t.cpu().numpy()
+        if not (flat[: d.off] == 0xAB).all() or not (flat[d.off + d.n * d.stride + 0:][-4000:] == 0xAB).all():
+            return f"write outside the destination n={n} {w}x{h}"
+    return None
+
+
 def main_ops(cases, seed0, case=ops_case, base=99000, name="ops"):
     bad = 0
     t_start = time.time()
@@ -237,9 +399,11 @@ def main_ops(cases, seed0, case=ops_case, base=99000, name="ops"):
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] in ("ops", "batch"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("ops", "batch", "abi"):
         n, s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 0
-        return main_ops(n, s0) if sys.argv[1] == "ops" else main_ops(n, s0, batch_case, 55000, "batch")
+        if sys.argv[1] == "ops":
+            return main_ops(n, s0)
+        return main_ops(n, s0, batch_case, 55000, "batch") if sys.argv[1] == "batch" else main_ops(n, s0, abi_case, 33000, "abi")
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
