@@ -111,17 +111,20 @@ def ops_case(rng):
             long = int(rng.choice([95, 96, 97, 101, 127, 128, 129, 201, 255, 256, 257, 300]))
             kw_, kh_ = (long, 1) if rng.random() < 0.5 else (1, long)
         it, op = int(rng.integers(1, 4)), int(rng.integers(0, 4))
-        got = cv2.morphologyEx(src, op, np.ones((kh_, kw_), np.uint8), iterations=it)
-        if not np.array_equal(got, fr.morphology_ex(src, op, (kw_, kh_), it)):
-            return f"morphologyEx {w}x{h} op={op} k=({kw_},{kh_}) it={it} binary={src is binary}"
-    kx, ky = 2 * int(rng.integers(0, 8)) + 1, 2 * int(rng.integers(0, 8)) + 1
-    sg = 0.0 if rng.random() < 0.5 else float(rng.uniform(0.3, 4.0))
-    if not np.array_equal(cv2.GaussianBlur(g, (kx, ky), sg), fr.gaussian_blur(g, (kx, ky), sg)):
-        return f"GaussianBlur {w}x{h} ({kx},{ky}) {sg}"
+        anchor = (-1, -1) if rng.random() < 0.7 else (int(rng.integers(0, kw_)), int(rng.integers(0, kh_)))
+        got = cv2.morphologyEx(src, op, np.ones((kh_, kw_), np.uint8), anchor=anchor, iterations=it)
+        if not np.array_equal(got, fr.morphology_ex(src, op, (kw_, kh_), it, anchor)):
+            return f"morphologyEx {w}x{h} op={op} k=({kw_},{kh_}) it={it} anchor={anchor} binary={src is binary}"
+    kx, ky = 2 * int(rng.integers(0, 16)) + 1, 2 * int(rng.integers(0, 16)) + 1
+    sg = 0.0 if rng.random() < 0.5 else float(rng.uniform(0.3, 6.0))
+    sgy = 0.0 if rng.random() < 0.7 else float(rng.uniform(0.3, 6.0))
+    border = int(rng.choice([4, 4, 1, 2, 0]))
+    if not np.array_equal(cv2.GaussianBlur(g, (kx, ky), sg, sigmaY=sgy, borderType=border), fr.gaussian_blur(g, (kx, ky), sg, sgy, border)):
+        return f"GaussianBlur {w}x{h} ({kx},{ky}) {sg} {sgy} border={border}"
     blk, cc = 2 * int(rng.integers(1, 21)) + 1, float(rng.uniform(-10, 10))
-    meth, typ = int(rng.integers(0, 2)), int(rng.integers(0, 2))
-    if not np.array_equal(cv2.adaptiveThreshold(g, 255, meth, typ, blk, cc), fr.adaptive_threshold(g, 255, meth, typ, blk, cc)):
-        return f"adaptiveThreshold {w}x{h} {meth} {typ} {blk} {cc}"
+    meth, typ, mv = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.choice([255, 255, 1, 77.6, 300]))
+    if not np.array_equal(cv2.adaptiveThreshold(g, mv, meth, typ, blk, cc), fr.adaptive_threshold(g, mv, meth, typ, blk, cc)):
+        return f"adaptiveThreshold {w}x{h} {mv} {meth} {typ} {blk} {cc}"
     lo, hi = float(rng.uniform(0, 300)), float(rng.uniform(0, 300))
     e = cv2.Canny(g, lo, hi)
     if not np.array_equal(e, fr.canny(g, lo, hi)):
