@@ -2,7 +2,8 @@
 pytest): python tests/fuzz_gpu.py [cases] [first seed] for the fused pass, python tests/fuzz_gpu.py ops
 [cases] [first seed] for every single operation, python tests/fuzz_gpu.py batch [cases] [first seed] for
 the batched helpers, strided / device inputs, rectangle erase and large shapes, python tests/fuzz_gpu.py abi
-[cases] [first seed] for the C entry points with minimal (16-byte) pitches, strides and base alignment.  Shapes are biased towards the tile, strip and
+[cases] [first seed] for the C entry points with minimal (16-byte) pitches, strides and base alignment,
+python tests/fuzz_gpu.py threads [cases] [first seed] for concurrent calls from four host threads.  Shapes are biased towards the tile, strip and
 word boundaries of the kernels (multiples of 32 / 64 / 128 / 248 / 256 +-1), batches towards the sizes
 at which the fused pass switches schedules (1, 63, 64, 65, 128+), parameters over the ranges the
 parsers use and beyond.  Prints one line per failing case and a summary; exit status 1 on any failure."""
@@ -383,6 +384,53 @@ def abi_case(rng):
     return None
 
 
+def threads_case(rng):
+    """Fused passes (chunked and not), HoughLinesP batches and segment passes issued at the same time
+    from four host threads on streams of their own."""
+    import threading
+
+    import torch
+
+    w, h = pick_dim(rng, 300), pick_dim(rng, 200)
+    jobs = []
+    for t in range(4):
+        n = int(rng.choice([1, 5, 64, 70, 130]))
+        while n > 1 and n * w * h > 3_000_000:
+            n = max(1, n // 2)
+        jobs.append((diagram(rng, n, h, w), int(rng.integers(0, 256)), bool(rng.random() < 0.3), bool(rng.random() < 0.8)))
+    out, errors = [None] * 4, []
+
+    def work(t):
+        imgs, tv, blur, hough = jobs[t]
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(4):
+                    r = ipa.front_end_batch(imgs, thresh_val=tv, blur=blur, hough=hough)
+                    segs = ipa.segments_batch(r.hlines)
+                    out[t] = (r.gray, r.thresh, r.vlines, r.hlines, r.edges, r.accum.cpu().numpy() if hough else None, segs)
+        except Exception as ex:
+            errors.append(f"{type(ex).__name__}: {ex}")
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if errors:
+        return "; ".join(errors)
+    for t in range(4):
+        imgs, tv, blur, hough = jobs[t]
+        n = len(imgs)
+        for b in sorted(set([0, n // 2, n - 1])):
+            exp = oracle_case(imgs[b], tv, 15, 15, 2, 50, 150, blur, hough, True)
+            for k in range(6):
+                if exp[k] is not None and not np.array_equal(out[t][k][b], exp[k]):
+                    return f"thread {t} n={n} {w}x{h} image {b} output {k}"
+            if not np.array_equal(np.asarray(out[t][6][b], dtype=np.int64).reshape(-1, 4), fr.external_boxes(exp[3])):
+                return f"thread {t} n={n} {w}x{h} image {b} segments"
+    return None
+
+
 def main_ops(cases, seed0, case=ops_case, base=99000, name="ops"):
     bad = 0
     t_start = time.time()
@@ -402,6 +450,8 @@ def main_ops(cases, seed0, case=ops_case, base=99000, name="ops"):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "threads":
+        return main_ops(int(sys.argv[2]) if len(sys.argv) > 2 else 50, int(sys.argv[3]) if len(sys.argv) > 3 else 0, threads_case, 11000, "threads")
     if len(sys.argv) > 1 and sys.argv[1] in ("ops", "batch", "abi"):
         n, s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 0
         if sys.argv[1] == "ops":

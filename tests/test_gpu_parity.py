@@ -946,6 +946,40 @@ def test_reversed_and_strided_numpy_views():
             assert np.array_equal(cv2.threshold(view, 100, 255, cv2.THRESH_BINARY_INV)[1], want)
 
 
+def test_fused_pass_from_several_host_threads():
+    # the library is re-entrant per (device, stream): chunked fused passes (64 images or more, helper
+    # streams of the library involved) issued at the same time from three host threads on streams of
+    # their own
+    import threading
+
+    from imageprocessing_amd.synth import synth_batch
+
+    h, w, n = 150, 200, 66
+    batches = [synth_batch(900 + 100 * t, n, h, w) for t in range(3)]
+    results, errors = [None] * 3, []
+
+    def work(t):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    r = cv2.front_end_batch(batches[t], thresh_val=100 + 20 * t, hough=True)
+                    results[t] = (r.gray, r.thresh, r.vlines, r.hlines, r.edges, r.accum.cpu().numpy())
+        except Exception as ex:  # reported by the main thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(3):
+        for b in (0, 31, 32, n - 1):
+            want = fr.front_end(batches[t][b], t=100 + 20 * t)
+            for got, exp in zip(results[t], want):
+                assert np.array_equal(got[b], exp), (t, b)
+
+
 def test_c_abi_from_a_plain_c_program():
     # tests/c_abi/front_end_c: hipMalloc + ipa_front_end_u8 + hipMemcpy, no Python or torch in the process;
     # it compares all five planes and the accumulator with the CPU restatement itself
