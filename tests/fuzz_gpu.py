@@ -87,6 +87,9 @@ def ops_case(rng):
     first operation whose result differs from the restatement, or None."""
     cv2 = ipa
     w, h = pick_dim(rng, 1100), pick_dim(rng, 700)
+    if rng.random() < 0.04:  # ribbons: one side up to the 65535 limit
+        long, short = int(rng.choice([4097, 16384, 32769, 65535, int(rng.integers(5000, 65536))])), int(rng.integers(1, 9))
+        w, h = (long, short) if rng.random() < 0.5 else (short, long)
     g = gray_image(rng, int(rng.integers(0, 4)), h, w)
     binary = gray_image(rng, int(rng.choice([1, 2])), h, w)
     if binary.max() > 0 and len(np.unique(binary)) > 2:
@@ -464,6 +467,9 @@ def main():
     for c in range(cases):
         rng = np.random.default_rng(77000 + seed0 + c)
         w, h = pick_dim(rng, 1100), pick_dim(rng, 700)
+        if rng.random() < 0.04:  # ribbons
+            long, short = int(rng.choice([4097, 16384, 32769, 65535, int(rng.integers(5000, 65536))])), int(rng.integers(1, 9))
+            w, h = (long, short) if rng.random() < 0.5 else (short, long)
         n = int(rng.choice([1, 1, 2, 3, 5, 63, 64, 65, 70, 96, 128, 131]))
         while n > 1 and n * w * h > 24_000_000:
             n = max(1, n // 2)
