@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     flush(b);
 }
 
-constexpr int HT_THREADS = 512;      // 8 waves per workgroup
+constexpr int HT_THREADS = 512;      // 8 waves per workgroup (16 when there are few workgroups)
 constexpr int HT_MAX_TILES = 4096;   // tiles per region (one workgroup)
 
 // bit 0 of each of the 4 bytes of x -> 4 adjacent bits
@@ -527,7 +527,8 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
 // atomic ORs; if the rim of the tile changed, the neighbouring tiles with WEAK pixels go on
 // the next round's list.  Rounds are separated by a workgroup barrier (which also drains
 // the stores) and an L1 invalidate, so a round sees everything the previous one wrote.
-__global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
                                                            int rt_x, int rt_y, int regions_x, int regions_y,
                                                            CannyWs W, PointSink sink)
 {
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int
     const int tx_base = rx * rt_x, ty_base = ry * rt_y;
     const int nx_t = min(rt_x, tiles_x - tx_base), ny_t = min(rt_y, tiles_y - ty_base);
 
-    for (int i = tid; i < HT_MAX_TILES / 32; i += HT_THREADS) {
+    for (int i = tid; i < HT_MAX_TILES / 32; i += NT) {
         s_inq[i] = 0;
         s_flag[i] = 0;
     }
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int
         s_cursor = 0;
     }
     __syncthreads();
-    for (int t = tid; t < nx_t * ny_t; t += HT_THREADS) {
+    for (int t = tid; t < nx_t * ny_t; t += NT) {
         const int lx = t % nx_t, ly = t / nx_t;
         if (W.has_weak[((size_t)b * tiles_y + ty_base + ly) * tiles_x + tx_base + lx]) {
             atomicOr(&s_flag[t >> 5], 1u << (t & 31));
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hyst_tiles(Plane dst, int w, int
             s_cnt[cur] = 0;
             s_cursor = 0;
         }
-        for (int i = tid; i < HT_MAX_TILES / 32; i += HT_THREADS) s_inq[i] = 0;
+        for (int i = tid; i < HT_MAX_TILES / 32; i += NT) s_inq[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before re-reading tiles
         __syncthreads();
         cur = nxt;
@@ -790,8 +791,13 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     const bool multi = regions_x * regions_y > 1;
     for (int guard = 0; guard < 100000; guard++) {
         if (multi) IPA_HIP(hipMemsetAsync(W.again, 0, 4, st));
-        hipLaunchKernelGGL(k_hyst_tiles, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x, tiles_y, rt_x,
-                           rt_y, regions_x, regions_y, W, sink);
+        // few workgroups (small batches, single images): twice the waves per workgroup
+        if (blocks < 1024)
+            hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink);
+        else
+            hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink);
         IPA_LAUNCH_CHECK();
         if (!multi) break;
         u32 again;
