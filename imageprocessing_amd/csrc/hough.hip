@@ -580,15 +580,18 @@ __global__ __launch_bounds__(256) void k_hough_peaks(const int32_t* __restrict__
 
 // Peak search guided by the per-segment maxima the voting kernel left behind: a cell can
 // only be a peak if it exceeds the threshold, so segments whose maximum does not are never
-// read.  One wave per accumulator row.
+// read.  `split` waves share one accumulator row (wave s takes the segments j with j % split == s):
+// 1 for large batches, more when a few images would otherwise leave most of the chip idle while
+// the rows near 0 and 90 degrees walk through their many hot segments one after the other.
 __global__ __launch_bounds__(256) void k_hough_peaks_seg(const int32_t* __restrict__ accum, size_t accum_stride,
                                                          const int32_t* __restrict__ segmax, int nsegs, int numangle,
                                                          int numrho, int threshold, u64* __restrict__ keys, int capacity,
-                                                         int32_t* __restrict__ counts)
+                                                         int32_t* __restrict__ counts, int split)
 {
     const int b = blockIdx.y;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n = (int)blockIdx.x * 4 + wv;
+    const int widx = (int)blockIdx.x * 4 + wv;
+    const int n = widx / split, part = widx - n * split;
     if (n >= numangle) return;
     const int lane = threadIdx.x & 63;
     const int ncols = numrho + 2;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256) void k_hough_peaks_seg(const int32_t* __restri
     const int32_t* sm = segmax + ((size_t)b * numangle + n) * nsegs;
     for (int j0 = 0; j0 < nsegs; j0 += 64) {
       // 64 segment maxima at a time: one load, one ballot, then only the hot segments
-      unsigned long long hot = __ballot(j0 + lane < nsegs && sm[j0 + lane] > threshold);
+      unsigned long long hot = __ballot(j0 + lane < nsegs && (j0 + lane) % split == part && sm[j0 + lane] > threshold);
       while (hot) {
         const int j = j0 + __ffsll((long long)hot) - 1;
         hot &= hot - 1;
@@ -996,9 +999,12 @@ IPA_EXPORT int ipa_hough_peaks_i32(const int32_t* accum, size_t accum_stride, co
         int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         if (seg_max) {
             const int nsegs = hough_segments(numrho);
-            hipLaunchKernelGGL(k_hough_peaks_seg, dim3((unsigned)cdiv(numangle, 4), nb), dim3(256), 0, st,
+            // about 8192 waves at least
+            int split = (int)(8192 / ((long long)batch * numangle));
+            split = split < 1 ? 1 : (split > nsegs ? nsegs : split);
+            hipLaunchKernelGGL(k_hough_peaks_seg, dim3((unsigned)cdiv(numangle * split, 4), nb), dim3(256), 0, st,
                                accum + (size_t)b0 * accum_stride, accum_stride, seg_max + (size_t)b0 * numangle * nsegs, nsegs,
-                               numangle, numrho, threshold, (u64*)keys + (size_t)b0 * capacity, capacity, peak_counts + b0);
+                               numangle, numrho, threshold, (u64*)keys + (size_t)b0 * capacity, capacity, peak_counts + b0, split);
             IPA_LAUNCH_CHECK();
             continue;
         }
