@@ -31,6 +31,7 @@ constexpr u8 WEAK = 1;
 struct CannyWs {
     u8* has_weak;   // per tile: the tile holds WEAK pixels
     u32* again;     // set when a tile of another workgroup's region has to be revisited
+    u8* pending;    // per tile, or nullptr: tiles of other regions that have to be revisited (instead of `again`)
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -530,7 +531,7 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
                                                            int rt_x, int rt_y, int regions_x, int regions_y,
-                                                           CannyWs W, PointSink sink)
+                                                           CannyWs W, PointSink sink, int seed_pending)
 {
     __shared__ u16 s_list[2][HT_MAX_TILES];
     __shared__ u32 s_inq[HT_MAX_TILES / 32];
@@ -557,10 +558,14 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
     __syncthreads();
     for (int t = tid; t < nx_t * ny_t; t += NT) {
         const int lx = t % nx_t, ly = t / nx_t;
-        if (W.has_weak[((size_t)b * tiles_y + ty_base + ly) * tiles_x + tx_base + lx]) {
+        const size_t gt = ((size_t)b * tiles_y + ty_base + ly) * tiles_x + tx_base + lx;
+        if (W.has_weak[gt]) {
             atomicOr(&s_flag[t >> 5], 1u << (t & 31));
-            const u32 pos = atomicAdd(&s_cnt[0], 1u);
-            s_list[0][pos] = (u16)t;
+            // seed_pending: only the tiles an earlier launch left marked start on the list
+            if (!seed_pending || W.pending[gt]) {
+                const u32 pos = atomicAdd(&s_cnt[0], 1u);
+                s_list[0][pos] = (u16)t;
+            }
         }
     }
     __syncthreads();
@@ -669,7 +674,9 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
                             }
                         }
                     } else if (W.has_weak[((size_t)b * tiles_y + gty) * tiles_x + gtx]) {
-                        atomicExch(W.again, 1u);  // belongs to another workgroup's region: one more launch
+                        // belongs to another workgroup's region: left to a later launch
+                        if (W.pending) W.pending[((size_t)b * tiles_y + gty) * tiles_x + gtx] = 1;
+                        else atomicExch(W.again, 1u);
                     }
                 }
             }
@@ -722,7 +729,7 @@ size_t canny_ws_bytes(int w, int h, int batch)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     size_t ntiles = (size_t)cdiv(w, TW) * cdiv(h, TH) * batch;
-    return align_up(ntiles, 256) + 512;
+    return 2 * align_up(ntiles, 256) + 512;
 }
 
 // Enqueues the whole detector.  Images of up to HT_MAX_TILES tiles (e.g. 4K) are
@@ -740,7 +747,24 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     const size_t ntiles = (size_t)ntiles_ll;
     CannyWs W;
     W.has_weak = (u8*)ws;
-    W.again = (u32*)((u8*)ws + align_up(ntiles, 256));
+    W.pending = nullptr;
+    u8* const pending = (u8*)ws + align_up(ntiles, 256);  // directly behind has_weak: one memset clears both
+    W.again = (u32*)((u8*)ws + 2 * align_up(ntiles, 256));
+    // Few images of at most HT_MAX_TILES tiles: one workgroup per image would leave the chip idle, so a
+    // first launch works on small regions side by side and marks the tiles across region borders that
+    // would have to be revisited; a second launch (one workgroup per image, started from the marked
+    // tiles only) then runs to the fixed point.  No host round trip, unlike the loop for huge images.
+    const int tiles_x0 = cdiv(w, TW), tiles_y0 = cdiv(h, TH);
+    static int side_env = -2;  // IPA_HYST_SMALL_SIDE: region side in tiles of the first launch (0 = off; default: by batch)
+    if (side_env == -2) {
+        const char* e = getenv("IPA_HYST_SMALL_SIDE");
+        side_env = e ? atoi(e) : -1;
+        if (side_env < -1 || side_env > 64) side_env = -1;
+    }
+    // measured on 4K images: 8 x 8 tiles for up to 4 images, 16 x 16 up to 32, one workgroup per image beyond
+    const int small_side = side_env >= 0 ? side_env : (batch <= 4 ? 8 : (batch <= 32 ? 16 : 0));
+    const bool two_step = small_side > 0 && batch < 128 && (long long)tiles_x0 * tiles_y0 <= HT_MAX_TILES &&
+                          (tiles_x0 > small_side || tiles_y0 > small_side);
     static int mode = -1;  // IPA_CANNY_MODE: 1 = streaming register kernel (default), 0 = LDS tile kernel
     if (mode < 0) {
         const char* e = getenv("IPA_CANNY_MODE");
@@ -752,7 +776,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         const bool stream_ok = w >= 4 && (unsigned long long)h * src.pitch < 0xffffffffull && (unsigned long long)h * dst.pitch < 0xffffffffull;
         if (mode == 1 && (stream_ok || sink.pts)) {
             IPA_REQUIRE(stream_ok, IPA_ERR_ARG, "Canny: image too small or too large for the fused edge-list path");
-            IPA_HIP(hipMemsetAsync(W.has_weak, 0, ntiles, st));
+            IPA_HIP(hipMemsetAsync(W.has_weak, 0, two_step ? align_up(ntiles, 256) + ntiles : ntiles, st));
             const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;
             IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
@@ -771,6 +795,23 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         IPA_LAUNCH_CHECK();
     }
     ProfScope ps(PROF_HYSTERESIS, st);
+    if (two_step) {
+        if (mode != 1) IPA_HIP(hipMemsetAsync(pending, 0, ntiles, st));  // (the tile kernel writes has_weak itself)
+        const int rx = cdiv(tiles_x, small_side), ry = cdiv(tiles_y, small_side);
+        CannyWs W1 = W;
+        W1.pending = pending;
+        hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)(rx * ry * batch)), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
+                           tiles_y, small_side, small_side, rx, ry, W1, sink, 0);
+        IPA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)batch), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
+                           tiles_y, tiles_x, tiles_y, 1, 1, W1, sink, 1);
+        IPA_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+        hipLaunchKernelGGL(k_hyst_final, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles,
+                           (const u8*)W.has_weak);
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
     // regions of at most HT_MAX_TILES tiles (64 x 64 tiles = 8192 x 2048 pixels)
     int rt_x = tiles_x, rt_y = tiles_y;
     if ((long long)rt_x * rt_y > HT_MAX_TILES) {
@@ -794,10 +835,10 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         // few workgroups (small batches, single images): twice the waves per workgroup
         if (blocks < 1024)
             hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
-                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink);
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink, 0);
         else
             hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
-                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink);
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink, 0);
         IPA_LAUNCH_CHECK();
         if (!multi) break;
         u32 again;

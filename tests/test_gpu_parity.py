@@ -301,6 +301,39 @@ def test_canny_long_weak_chains_cross_many_tiles():
     assert np.array_equal(cv2.Canny(g2, 50, 150), fr.canny(g2, 50, 150))
 
 
+def _weak_serpentine(h, w):
+    """One connected low-contrast curve (weak only) that sweeps the image row band by row band."""
+    g = np.full((h, w), 200, np.uint8)
+    k, y = 0, 40
+    while y + 80 < h:
+        g[y:y + 20, 30:w - 30] = 180
+        if y + 60 + 20 + 80 < h + 60:
+            xs = slice(w - 50, w - 30) if k % 2 == 0 else slice(30, 50)
+            g[y:y + 80, xs] = 180
+        y += 60
+        k += 1
+    return g
+
+
+@pytest.mark.parametrize("n", [1, 5, 40])
+def test_canny_hysteresis_across_regions(n):
+    # small batches resolve hysteresis region by region first and finish with one workgroup per image:
+    # a weak curve that crosses every region border many times, seeded at one point only
+    h, w = 1210, 2300
+    g = _weak_serpentine(h, w)
+    assert fr.canny(g, 50, 150).sum() == 0
+    g[38:44, 28:34] = 0  # the only strong pixels
+    want = fr.canny(g, 50, 150)
+    assert want.sum() > 255 * 20000
+    batch = np.stack([g if i % 2 == 0 else np.ascontiguousarray(g[::-1, ::-1]) for i in range(n)])
+    pad = np.stack([batch] * 3, axis=-1)  # gray as BGR: the fused pass is the batched entry point
+    r = cv2.front_end_batch(pad, hough=False)
+    for i in range(n):
+        exp = want if i % 2 == 0 else fr.canny(batch[i], 50, 150)
+        assert np.array_equal(r.edges[i], exp), i
+    assert np.array_equal(cv2.Canny(g, 50, 150), want)
+
+
 def test_canny_noisy_whiteboard():
     bgr = uml_like(9000, 500, 900, noise=6)
     g = fr.bgr2gray(bgr)
