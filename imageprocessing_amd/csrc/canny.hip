@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(Plane src, Plane dst, int w, 
 // neighbours (strips overlap by 8 pixels), so a strip yields 248 columns.  Rows are read
 // and written as contiguous 256-byte segments, and neighbouring strips advance together,
 // which keeps the HBM access pattern row-sequential.
-constexpr int ST_ROWS = 64;
+constexpr int ST_ROWS = 64, ST_ROWS_SHORT = 16;
 constexpr int ST_COLS = 248;
 
 struct MagRow {
@@ -295,7 +295,10 @@ __device__ __forceinline__ u32 nms_pair(u32 m, u32 ax, u32 ay, u32 sgn, u32 CL, 
     return out;
 }
 
-template <bool EMIT>
+// ROWS = rows per band (ROWS + 2 a multiple of 3): 64 for batches, 16 when a launch would otherwise have
+// too few waves to fill the chip (a wave walks its band row by row, so short bands also shorten the
+// longest dependent chain of the launch)
+template <bool EMIT, int ROWS>
 __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
                                                       long long nwaves, int low, int high, int tiles_x, int tiles_y,
                                                       CannyWs W, PointSink sink)
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     const int sx = (int)(wid - t * (u32)strips_x);
     const int b = (int)(t / (u32)bands), band = (int)(t - (u32)b * (u32)bands);
     const int x = sx * ST_COLS - 4 + 4 * lane;
-    const int y0 = band * ST_ROWS, y1 = min(y0 + ST_ROWS, h);
+    static_assert((ROWS + 2) % 3 == 0, "the row loop is unrolled by three");
+    const int y0 = band * ROWS, y1 = min(y0 + ROWS, h);
     // magnitude is 0 outside the image
     const u32 cm01 = ((x >= 0 && x < w) ? 0x0000ffffu : 0u) | ((x + 1 >= 0 && x + 1 < w) ? 0xffff0000u : 0u);
     const u32 cm23 = ((x + 2 >= 0 && x + 2 < w) ? 0x0000ffffu : 0u) | ((x + 3 >= 0 && x + 3 < w) ? 0xffff0000u : 0u);
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     // fixed trip count (rows past the image are clamped reads and skipped writes) so that the
     // loop can be unrolled by three, the period of the rolling row registers
 #pragma unroll 3
-    for (int it = 0; it < ST_ROWS + 2; it++) {
+    for (int it = 0; it < ROWS + 2; it++) {
         const int yy = y0 + it;
         const u32 g = gq[it % 3];
         gq[it % 3] = load_row(yy + 3);
@@ -777,16 +781,22 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         if (mode == 1 && (stream_ok || sink.pts)) {
             IPA_REQUIRE(stream_ok, IPA_ERR_ARG, "Canny: image too small or too large for the fused edge-list path");
             IPA_HIP(hipMemsetAsync(W.has_weak, 0, two_step ? align_up(ntiles, 256) + ntiles : ntiles, st));
-            const int strips_x = cdiv(w, ST_COLS), bands = cdiv(h, ST_ROWS);
+            const int strips_x = cdiv(w, ST_COLS);
+            // short bands while 64-row bands would give fewer than 4096 waves (16 per CU)
+            const bool short_bands = (long long)strips_x * cdiv(h, ST_ROWS) * batch < 4096;
+            const int bands = cdiv(h, short_bands ? ST_ROWS_SHORT : ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;
             IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
             static const size_t pad = lds_pad_kib("IPA_PAD_CANNY");
-            if (sink.pts)
-                hipLaunchKernelGGL(k_canny_stream<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), pad, st, src, dst, w, h,
-                                   strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
-            else
-                hipLaunchKernelGGL(k_canny_stream<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), pad, st, src, dst, w, h,
-                                   strips_x, bands, nwaves, low, high, tiles_x, tiles_y, W, sink);
+            const dim3 grid((unsigned)((nwaves + 3) / 4));
+#define IPA_CANNY_STREAM(EMITV, ROWSV)                                                                              \
+    hipLaunchKernelGGL((k_canny_stream<EMITV, ROWSV>), grid, dim3(256), pad, st, src, dst, w, h, strips_x, bands, nwaves, \
+                       low, high, tiles_x, tiles_y, W, sink)
+            if (sink.pts && short_bands) IPA_CANNY_STREAM(true, ST_ROWS_SHORT);
+            else if (sink.pts) IPA_CANNY_STREAM(true, ST_ROWS);
+            else if (short_bands) IPA_CANNY_STREAM(false, ST_ROWS_SHORT);
+            else IPA_CANNY_STREAM(false, ST_ROWS);
+#undef IPA_CANNY_STREAM
         } else {
             IPA_REQUIRE(!sink.pts, IPA_ERR_ARG, "Canny: the LDS tile kernel cannot emit the edge-pixel list");
             hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)ntiles), dim3(256), 0, st, src, dst, w, h, tiles_x, tiles_y, low,
