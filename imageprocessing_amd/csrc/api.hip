@@ -133,16 +133,24 @@ static size_t chunk_ws_bytes(int width, int height, int batch, int max_points)
 // Large batches run as several chunks, each with its own part of the workspace, so that stages
 // bound by different units of the chip can run side by side (see ipa_front_end_u8).
 constexpr int IPA_MAX_CHUNKS = 8;
-static int pipeline_chunks(int batch)
+static int pipeline_chunks(int batch, int width, int height)
 {
-    static int pipe = -1;  // IPA_PIPELINE=<chunks>; 0 or 1: one chain on the caller's stream
-    if (pipe < 0) {
+    static int pipe = -2;  // IPA_PIPELINE=<chunks>; 0 or 1: one chain on the caller's stream; unset: by size
+    if (pipe == -2) {
         const char* e = getenv("IPA_PIPELINE");
-        pipe = e ? atoi(e) : 4;
+        pipe = e ? atoi(e) : -1;
         if (pipe > IPA_MAX_CHUNKS) pipe = IPA_MAX_CHUNKS;
     }
+    // Measured on 4K images (ms per batch with 1 / 2 / 3 / 4 chunks): 128 images 4.46 / 4.62 / - / 5.15,
+    // 256: 8.56 / 8.30 / - / 8.94, 512: 16.4 / 15.6 / - / 15.7, 768: - / 22.8 / 22.0 / 22.5,
+    // 1024: - / 29.6 / 29.4 / 29.0 -- a chunk wants about 1.5 gigapixels before overlap pays.
+    int by_size = 1;
+    const double gpx = (double)batch * width * height * 1e-9;
+    if (gpx >= 7.4) by_size = 4;
+    else if (gpx >= 5.3) by_size = 3;
+    else if (gpx >= 1.46) by_size = 2;
     // per-stage timing wants the stages one after the other, each over the whole batch
-    int k = g_prof_on ? 1 : pipe;
+    int k = g_prof_on ? 1 : (pipe >= 0 ? pipe : by_size);
     while (k > 1 && batch / k < 32) k--;  // chunks of at least 32 images
     return k < 1 ? 1 : k;
 }
@@ -383,7 +391,7 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     IPA_REQUIRE(ws && ws_bytes >= ipa_front_end_workspace_bytes(width, height, batch, max_points), IPA_ERR_WORKSPACE,
                 "front_end: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const int k = pipeline_chunks(batch);
+    const int k = pipeline_chunks(batch, width, height);
     hipStream_t s2 = k > 1 ? side_stream(1) : nullptr;
     const int nk = s2 ? k : 1;
     int na = 0, nr = 0;
