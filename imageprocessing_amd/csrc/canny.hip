@@ -765,8 +765,8 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         side_env = e ? atoi(e) : -1;
         if (side_env < -1 || side_env > 64) side_env = -1;
     }
-    // measured on 4K images: 8 x 8 tiles for up to 4 images, 16 x 16 up to 32, one workgroup per image beyond
-    const int small_side = side_env >= 0 ? side_env : (batch <= 4 ? 8 : (batch <= 32 ? 16 : 0));
+    // measured on 4K images: 8 x 8 tiles for up to 4 images, 16 x 16 up to 48, one workgroup per image beyond
+    const int small_side = side_env >= 0 ? side_env : (batch <= 4 ? 8 : (batch <= 48 ? 16 : 0));
     const bool two_step = small_side > 0 && batch < 128 && (long long)tiles_x0 * tiles_y0 <= HT_MAX_TILES &&
                           (tiles_x0 > small_side || tiles_y0 > small_side);
     static int mode = -1;  // IPA_CANNY_MODE: 1 = streaming register kernel (default), 0 = LDS tile kernel

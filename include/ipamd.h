@@ -210,7 +210,7 @@ int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
  * newVersion3/detectHorizontalVerticalLines.py:61; "New Version/detectArrow.py":8.
  * Hysteresis runs to its fixed point without any host interaction for images of
  * at most 4096 tiles of 128x32 pixels (one workgroup per image; for batches of up
- * to 32 images a first launch works on small regions side by side and a second one
+ * to 48 images a first launch works on small regions side by side and a second one
  * finishes what crosses their borders); larger images are resolved region by
  * region and the call then synchronises `stream` once per convergence check. */
 size_t ipa_canny_workspace_bytes(int width, int height, int batch);

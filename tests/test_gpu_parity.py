@@ -315,7 +315,7 @@ def _weak_serpentine(h, w):
     return g
 
 
-@pytest.mark.parametrize("n", [1, 5, 40])
+@pytest.mark.parametrize("n", [1, 5, 40, 60])
 def test_canny_hysteresis_across_regions(n):
     # small batches resolve hysteresis region by region first and finish with one workgroup per image:
     # a weak curve that crosses every region border many times, seeded at one point only
