@@ -98,11 +98,14 @@ __device__ __forceinline__ u32 bytes_to_bits(u32 x) { return ((x & 0x01010101u) 
 // 1 in bit 0 of every non-zero byte
 __device__ __forceinline__ u32 nonzero_bytes(u32 v) { return ((v | ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; }
 
-__global__ __launch_bounds__(256) void k_hough_compact2(Plane src, int w, int h, int cpr, u32* __restrict__ pts,
-                                                        size_t pts_stride, u32 cap, int32_t* __restrict__ counts, int spread)
+// NW = waves (= image rows) per block: 4 for batches; 16 for a few images, whose blocks would otherwise
+// queue up at the image's one counter.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_hough_compact2(Plane src, int w, int h, int cpr, u32* __restrict__ pts,
+                                                             size_t pts_stride, u32 cap, int32_t* __restrict__ counts, int spread)
 {
     __shared__ u32 s_pts[CP_STAGE];
-    __shared__ u32 row_tot[4 * ROWS_PER_LANE];
+    __shared__ u32 row_tot[NW * ROWS_PER_LANE];
     __shared__ u32 s_base;
     const int b = blockIdx.x;
     const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void k_hough_compact2(Plane src, int w, int h,
     __syncthreads();
     u32 total = 0, row_base[ROWS_PER_LANE] = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 4 * ROWS_PER_LANE; r++) {
+    for (int r = 0; r < NW * ROWS_PER_LANE; r++) {
         const u32 t = row_tot[r];
 #pragma unroll
         for (int k = 0; k < ROWS_PER_LANE; k++)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void k_hough_compact2(Plane src, int w, int h,
         // of one vote instruction lie on different features and rarely share an LDS bin.
         u32 M = 1;
         if (spread && total >= 128) M = total % 61 ? 61 : (total % 67 ? 67 : 71);
-        for (u32 i = tid; i < total; i += 256)
+        for (u32 i = tid; i < total; i += 64 * NW)
             if (base + i < cap) out[base + i] = s_pts[(i * M) % total];
     }
 }
@@ -749,14 +752,23 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             // The four rows of a block are gridDim.z apart.  An odd distance: rows a multiple of 32 apart
             // (any height that is a multiple of 128) put the bins of theta = 90 degrees of all four into
             // one LDS bank, and the vote kernel then serialises (measured: 10x on that angle).
-            const dim3 grid((unsigned)batch, (unsigned)cdiv(cpr, 64 * ROWS_PER_LANE), (unsigned)(cdiv(h, 4) | 1));
+            static int nw_env = -1;  // IPA_COMPACT_ROWS: 4 or 16 rows per block (default: by launch size)
+            if (nw_env < 0) {
+                const char* e = getenv("IPA_COMPACT_ROWS");
+                nw_env = e ? atoi(e) : 0;
+            }
+            const int nw = nw_env == 4 || nw_env == 16 ? nw_env : ((long long)batch * cdiv(h, 4) < 16384 ? 16 : 4);  // rows per block
+            const dim3 grid((unsigned)batch, (unsigned)cdiv(cpr, 64 * ROWS_PER_LANE), (unsigned)(cdiv(h, nw) | 1));
             static int spread = -1;  // IPA_COMPACT_SPREAD=0 keeps raster order inside a block
             if (spread < 0) {
                 const char* e = getenv("IPA_COMPACT_SPREAD");
                 spread = e ? atoi(e) : 1;
             }
             static const size_t pad = lds_pad_kib("IPA_PAD_COMPACT");
-            hipLaunchKernelGGL(k_hough_compact2, grid, rows_block(), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
+            if (nw == 16)
+                hipLaunchKernelGGL(k_hough_compact2<16>, grid, dim3(64, 16), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
+            else
+                hipLaunchKernelGGL(k_hough_compact2<4>, grid, rows_block(), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
             IPA_LAUNCH_CHECK();
         } else {
             IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL - (1 << 22), IPA_ERR_ARG, "HoughLines: image too large");
