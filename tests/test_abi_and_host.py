@@ -187,3 +187,13 @@ def test_c_example_builds_and_links():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "tests", "c_abi")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(root, "tests", "c_abi", "front_end_c"))
+
+
+def test_fuzz_driver_compiles():
+    # tests/fuzz_gpu.py is run by hand on a GPU box; here only that it parses and names its modes
+    import ast
+
+    src = open(os.path.join(ROOT, "tests", "fuzz_gpu.py")).read()
+    tree = ast.parse(src)
+    names = {n.name for n in tree.body if isinstance(n, ast.FunctionDef)}
+    assert {"main", "ops_case", "batch_case", "abi_case", "threads_case"} <= names
