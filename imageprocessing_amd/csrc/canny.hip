@@ -780,7 +780,8 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         const bool stream_ok = w >= 4 && (unsigned long long)h * src.pitch < 0xffffffffull && (unsigned long long)h * dst.pitch < 0xffffffffull;
         if (mode == 1 && (stream_ok || sink.pts)) {
             IPA_REQUIRE(stream_ok, IPA_ERR_ARG, "Canny: image too small or too large for the fused edge-list path");
-            IPA_HIP(hipMemsetAsync(W.has_weak, 0, two_step ? align_up(ntiles, 256) + ntiles : ntiles, st));
+            // (whole multiples of 256 bytes: the runtime then clears them with one kernel instead of two)
+            IPA_HIP(hipMemsetAsync(W.has_weak, 0, (two_step ? 2 : 1) * align_up(ntiles, 256), st));
             const int strips_x = cdiv(w, ST_COLS);
             // short bands while 64-row bands would give fewer than 4096 waves (16 per CU)
             const bool short_bands = (long long)strips_x * cdiv(h, ST_ROWS) * batch < 4096;

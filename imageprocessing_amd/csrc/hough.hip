@@ -705,6 +705,22 @@ PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, 
     return k;
 }
 
+// accum[b * stride + i] = 0 for i < cells, every image b = blockIdx.y
+__global__ __launch_bounds__(256) void k_zero_i32(int32_t* __restrict__ accum, size_t stride, size_t cells)
+{
+    int32_t* p = accum + (size_t)blockIdx.y * stride;
+    // dwords up to the first 16-byte boundary, then 16 bytes per lane, then what is left
+    const size_t head = (size_t)((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    const size_t h0 = head < cells ? head : cells;
+    const size_t n4 = (cells - h0) / 4;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+    if (gid < h0) p[gid] = 0;
+    uint4* q = (uint4*)(p + h0);
+    for (size_t i = gid; i < n4; i += gsz) q[i] = make_uint4(0, 0, 0, 0);
+    const size_t t0 = h0 + n4 * 4;
+    if (gid < cells - t0) p[t0 + gid] = 0;
+}
+
 // phase HOUGH_VOTE_ONLY: the per-image point lists (layout of hough_point_sink) and point_counts
 // already exist (made by the Canny kernels or by an earlier HOUGH_COMPACT_ONLY call); otherwise they
 // are compacted from `src` here.
@@ -880,9 +896,15 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         else if ((long long)w * h >= (1 << 22) && wgs < 768) A.slices = (int)(1536 / wgs > 16 ? 16 : 1536 / wgs);
         if (A.slices < 1) A.slices = 1;
     }
-    if (A.slices > 1)
-        for (int b = 0; b < batch; b++)
-            IPA_HIP(hipMemsetAsync(accum + (size_t)b * accum_stride, 0, sizeof(int32_t) * (size_t)(numangle + 2) * (numrho + 2), st));
+    if (A.slices > 1) {
+        // one launch for all images (a runtime memset of a size that is no multiple of 16 bytes is two
+        // kernels per image, and this path is the one of single images, whose pass is a chain of short
+        // dependent launches)
+        const size_t cells = (size_t)(numangle + 2) * (numrho + 2);
+        hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)(cells / 1024 < 2048 ? cells / 1024 + 1 : 2048), (unsigned)batch), dim3(256), 0, st,
+                           accum, accum_stride, cells);
+        IPA_LAUNCH_CHECK();
+    }
     A.segmax = (tgs && A.slices == 1) ? seg_max : nullptr;
     const bool segmax_after = seg_max && A.slices > 1;  // computed from the finished accumulator
     if (seg_max && !A.segmax && !segmax_after)  // this kernel variant does not produce the maxima: mark every segment as worth reading
