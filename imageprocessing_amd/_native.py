@@ -26,6 +26,8 @@ SIGNATURES = {
     "ipa_version": (_i, []),
     "ipa_last_error": (C.c_char_p, []),
     "ipa_pitch_for": (_sz, [_sz]),
+    "ipa_set_option": (_i, [C.c_char_p, _i]),
+    "ipa_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "ipa_profile_enable": (_i, [_i]),
     "ipa_profile_stage_count": (_i, []),
     "ipa_profile_stage_name": (C.c_char_p, [_i]),
@@ -60,6 +62,7 @@ SIGNATURES = {
     "ipa_hough_lines_p_workspace_bytes": (_sz, [_i, _i, _i, _d, _d, _i]),
     "ipa_hough_lines_p_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _d, _d, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "ipa_front_end_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ipa_front_end_chunks": (_i, [_i, _i, _i]),
     "ipa_front_end_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _i, _vp,
                               _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _sz, _vp]),
 }

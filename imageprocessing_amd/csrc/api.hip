@@ -19,6 +19,8 @@ void ipa_set_error(const char* fmt, ...)
 IPA_EXPORT int ipa_version(void) { return 100; }
 
 // ---- per-stage timing ---------------------------------------------------------
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 namespace {
@@ -28,7 +30,7 @@ struct ProfRec {
     bool ok;
 };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<ProfRec> g_prof_recs;
 std::vector<ProfRec> g_prof_open;
 }  // namespace
@@ -94,6 +96,59 @@ IPA_EXPORT int ipa_profile_collect(double* ms, int* launches)
     return IPA_OK;
 }
 IPA_EXPORT const char* ipa_last_error(void) { return g_err; }
+
+// ---- run-time options ---------------------------------------------------------
+// Schedule switches of the fused front-end.  Their defaults come from the environment the first
+// time one is needed (IPA_PIPELINE, IPA_OVERLAP, IPA_PHASED, IPA_HEAD_START); ipa_set_option changes
+// them for the calls that follow, from any thread.
+namespace {
+enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_COUNT };
+const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks"};
+const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START"};
+const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000};
+std::atomic<int> g_opt[OPT_COUNT];
+std::once_flag g_opt_once;
+void options_init()
+{
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < OPT_COUNT; i++) {
+            const char* e = getenv(g_opt_env[i]);
+            g_opt[i].store(e ? atoi(e) : g_opt_default[i]);
+        }
+    });
+}
+int option(int which)
+{
+    options_init();
+    return g_opt[which].load(std::memory_order_relaxed);
+}
+}  // namespace
+
+IPA_EXPORT int ipa_set_option(const char* name, int value)
+{
+    IPA_REQUIRE(name != nullptr, IPA_ERR_ARG, "set_option: NULL name");
+    options_init();
+    for (int i = 0; i < OPT_COUNT; i++)
+        if (!strcmp(name, g_opt_name[i])) {
+            g_opt[i].store(value);
+            return IPA_OK;
+        }
+    ipa_set_error("set_option: unknown option '%s'", name);
+    return IPA_ERR_ARG;
+}
+
+IPA_EXPORT int ipa_get_option(const char* name, int* value)
+{
+    IPA_REQUIRE(name != nullptr && value != nullptr, IPA_ERR_ARG, "get_option: NULL argument");
+    for (int i = 0; i < OPT_COUNT; i++)
+        if (!strcmp(name, g_opt_name[i])) {
+            *value = option(i);
+            return IPA_OK;
+        }
+    ipa_set_error("get_option: unknown option '%s'", name);
+    return IPA_ERR_ARG;
+}
+
 IPA_EXPORT size_t ipa_pitch_for(size_t row_bytes) { return align_up(row_bytes ? row_bytes : 1, 256); }
 
 int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, int32_t* vmax,
@@ -135,24 +190,25 @@ static size_t chunk_ws_bytes(int width, int height, int batch, int max_points)
 constexpr int IPA_MAX_CHUNKS = 8;
 static int pipeline_chunks(int batch, int width, int height)
 {
-    static int pipe = -2;  // IPA_PIPELINE=<chunks>; 0 or 1: one chain on the caller's stream; unset: by size
-    if (pipe == -2) {
-        const char* e = getenv("IPA_PIPELINE");
-        pipe = e ? atoi(e) : -1;
-        if (pipe > IPA_MAX_CHUNKS) pipe = IPA_MAX_CHUNKS;
+    // option pipeline_chunks: -1 = by size; 0 or 1 = one chain on the caller's stream; n = that many chunks
+    int pipe = option(OPT_PIPELINE);
+    if (pipe > IPA_MAX_CHUNKS) pipe = IPA_MAX_CHUNKS;
+    // per-stage timing wants the stages one after the other, each over the whole batch
+    if (g_prof_on) return 1;
+    if (pipe >= 0) {  // forced: any chunk count the batch can fill
+        if (pipe > batch) pipe = batch;
+        return pipe < 1 ? 1 : pipe;
     }
     // Measured on 4K images (ms per batch with 1 / 2 / 3 / 4 chunks): 128 images 4.46 / 4.62 / - / 5.15,
     // 256: 8.56 / 8.30 / - / 8.94, 512: 16.4 / 15.6 / - / 15.7, 768: - / 22.8 / 22.0 / 22.5,
     // 1024: - / 29.6 / 29.4 / 29.0 -- a chunk wants about 1.5 gigapixels before overlap pays.
-    int by_size = 1;
+    int k = 1;
     const double gpx = (double)batch * width * height * 1e-9;
-    if (gpx >= 7.4) by_size = 4;
-    else if (gpx >= 5.3) by_size = 3;
-    else if (gpx >= 1.46) by_size = 2;
-    // per-stage timing wants the stages one after the other, each over the whole batch
-    int k = g_prof_on ? 1 : (pipe >= 0 ? pipe : by_size);
+    if (gpx >= 7.4) k = 4;
+    else if (gpx >= 5.3) k = 3;
+    else if (gpx >= 1.46) k = 2;
     while (k > 1 && batch / k < 32) k--;  // chunks of at least 32 images
-    return k < 1 ? 1 : k;
+    return k;
 }
 // images [lo, hi) of chunk c out of k
 static void chunk_range(int batch, int k, int c, int* lo, int* hi)
@@ -160,6 +216,12 @@ static void chunk_range(int batch, int k, int c, int* lo, int* hi)
     const int base = batch / k, rem = batch % k;
     *lo = c * base + (c < rem ? c : rem);
     *hi = *lo + base + (c < rem ? 1 : 0);
+}
+
+IPA_EXPORT int ipa_front_end_chunks(int width, int height, int batch)
+{
+    if (width <= 0 || height <= 0 || batch <= 0) return 0;
+    return pipeline_chunks(batch, width, height);
 }
 
 IPA_EXPORT size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points)
@@ -179,18 +241,51 @@ IPA_EXPORT size_t ipa_front_end_workspace_bytes(int width, int height, int batch
 }
 
 namespace {
-// One helper stream per device: the two opens only depend on the gray kernel and are bound by
-// HBM writes, the Canny kernels by the vector ALUs, so they run side by side.  The helper
-// stream is joined back into the caller's stream before the call returns.
+// Helper streams: the two opens only depend on the gray kernel and are bound by HBM writes, the Canny
+// kernels by the vector ALUs, so they run side by side; the second helper carries the other half of a
+// pipelined batch.  Every (device, caller's stream) gets a pair of its own, so that calls issued from
+// several host threads on streams of their own do not wait for each other; both are joined back into
+// the caller's stream before a call returns.  Beyond SIDE_MAX_PAIRS pairs per process the pairs are
+// shared (correct, but such calls then queue behind each other).
+constexpr size_t SIDE_MAX_PAIRS = 64;
+struct SidePair {
+    hipStream_t s[2] = {nullptr, nullptr};
+};
 std::mutex g_side_mu;
-hipStream_t g_side_stream[2][64] = {};
-// which = 0: stream of the opens, 1: stream of the second half of a pipelined batch
-hipStream_t side_stream(int which)
+std::map<std::pair<int, hipStream_t>, SidePair> g_side;
+
+// The device `st` belongs to must be the current one (helper streams and the library's launches go to
+// the current device).  Returns the device, or -1 with the error text set.
+int stream_device(hipStream_t st)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) {
+        ipa_set_error("front_end: no current device");
+        return -1;
+    }
+    if (st) {
+        hipDevice_t sd = -1;
+        if (hipStreamGetDevice(st, &sd) == hipSuccess && (int)sd != cur) {
+            ipa_set_error("front_end: the stream belongs to device %d but device %d is current", (int)sd, cur);
+            return -1;
+        }
+    }
+    return cur;
+}
+
+// which = 0: stream of the opens, 1: stream of the second half of a pipelined batch
+hipStream_t side_stream(int which, int dev, hipStream_t caller)
+{
     std::lock_guard<std::mutex> lk(g_side_mu);
-    hipStream_t& sref = g_side_stream[which][dev];
+    auto key = std::make_pair(dev, caller);
+    auto it = g_side.find(key);
+    if (it == g_side.end()) {
+        if (g_side.size() >= SIDE_MAX_PAIRS) {  // share the pair of another stream of this device
+            for (it = g_side.begin(); it != g_side.end() && it->first.first != dev; ++it) {}
+        }
+        if (it == g_side.end()) it = g_side.emplace(key, SidePair()).first;
+    }
+    hipStream_t& sref = it->second.s[which];
     if (!sref && hipStreamCreateWithFlags(&sref, hipStreamNonBlocking) != hipSuccess) sref = nullptr;
     return sref;
 }
@@ -207,6 +302,8 @@ struct Chunk {
     int32_t *accum, *seg_max, *point_counts;
     size_t accum_stride;
     int max_points, width, height, batch, tv, KV, AV, KH, AH, blur5x5, lo, hi;
+    int dev;             // current device = device of the caller's stream
+    hipStream_t caller;  // the caller's stream (key of the helper streams)
     FrontWs L;
     u32* bits;
     void *canny_ws, *hough_ws, *blur_ws;
@@ -318,18 +415,32 @@ int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t s
                            (lists_ready || fused_points()) ? HOUGH_VOTE_ONLY : HOUGH_ALL, resident_wgs, st);
 }
 
-struct Events {
+// Events that order the helper streams.  They come from a per-thread pool that lives as long as the
+// thread: a wait enqueued on a stream refers to the record made before it, so an event may be
+// recorded again by a later call while earlier work is still in flight.
+struct EventPool {
     std::vector<hipEvent_t> ev;
-    ~Events()
+    size_t next = 0;
+    ~EventPool()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     }
+};
+thread_local EventPool g_events;
+struct Events {
     hipEvent_t make()
     {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        ev.push_back(e);
-        return e;
+        EventPool& P = g_events;
+        if (P.next == P.ev.size()) {
+            if (P.ev.size() >= 64) {  // more than a call ever needs: start over
+                P.next = 0;
+            } else {
+                hipEvent_t e = nullptr;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+                P.ev.push_back(e);
+            }
+        }
+        return P.ev[P.next++];
     }
 };
 
@@ -358,12 +469,8 @@ static int front_end_chunk(const Chunk& C, hipStream_t st, hipEvent_t after_gray
     int rc = stage_gray(C, st);
     if (rc) return rc;
     if (after_gray) IPA_HIP(hipEventRecord(after_gray, st));
-    static int overlap = -1;  // IPA_OVERLAP=0: everything on the caller's stream
-    if (overlap < 0) {
-        const char* e = getenv("IPA_OVERLAP");
-        overlap = e ? atoi(e) : 1;
-    }
-    hipStream_t so = overlap && !g_prof_on ? side_stream(0) : nullptr;  // stream of the opens
+    // option overlap = 0: everything on the caller's stream
+    hipStream_t so = option(OPT_OVERLAP) && !g_prof_on ? side_stream(0, C.dev, C.caller) : nullptr;  // stream of the opens
     Events E;
     if (so && stream_after(so, st, E) != IPA_OK) so = nullptr;
     if (!so) so = st;
@@ -391,8 +498,10 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     IPA_REQUIRE(ws && ws_bytes >= ipa_front_end_workspace_bytes(width, height, batch, max_points), IPA_ERR_WORKSPACE,
                 "front_end: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    const int dev = stream_device(st);
+    if (dev < 0) return IPA_ERR_ARG;
     const int k = pipeline_chunks(batch, width, height);
-    hipStream_t s2 = k > 1 ? side_stream(1) : nullptr;
+    hipStream_t s2 = k > 1 ? side_stream(1, dev, st) : nullptr;
     const int nk = s2 ? k : 1;
     int na = 0, nr = 0;
     if (accum) ipa_hough_dims(width, height, 1.0, M_PI / 180, &na, &nr);
@@ -411,6 +520,8 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
                             point_counts ? point_counts + lo : nullptr, width, height, hi - lo, thresh_val, vert_len,
                             horiz_len, iterations, canny_lo, canny_hi, blur5x5, (u8*)ws + ws_off, wsc);
         if (rc) return rc;
+        C[c].dev = dev;
+        C[c].caller = st;
         ws_off += wsc;
     }
     if (nk == 1) return front_end_chunk(C[0], st);
@@ -418,26 +529,17 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
     Events E;
     int rc = stream_after(s2, st, E);  // the helper stream starts behind the work already queued on the caller's stream
     if (rc) return rc;
-    static int phased = -1;  // IPA_PHASED=0: the staggered schedule also when there is a Hough stage
-    if (phased < 0) {
-        const char* e = getenv("IPA_PHASED");
-        phased = e ? atoi(e) : 1;
-    }
-    if (accum && phased) {
+    // option phased = 0: the staggered schedule also when there is a Hough stage
+    if (accum && option(OPT_PHASED)) {
         // The vote of chunk c (LDS atomics) runs beside the binarisation of chunk c+1 (HBM): it is
         // launched first, as one workgroup per CU that stays until all its work is done, and the
         // streaming kernels fill the other half of every CU.  Launched the other way round the
         // streaming kernels' small workgroups would keep refilling the CUs and the vote's large ones
         // would wait.  The Canny stage (which wants the whole chip) follows when both are done.
-        int cus = 0, dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 0;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         cus &= ~7;
-        static int head_ticks = -1;  // IPA_HEAD_START: head start of the vote kernel in 10 ns ticks
-        if (head_ticks < 0) {
-            const char* e = getenv("IPA_HEAD_START");
-            head_ticks = e ? atoi(e) : 3000;
-        }
+        const int head_ticks = option(OPT_HEAD_START);  // head start of the vote kernel in 10 ns ticks
         rc = stage_gray(C[0], st);
         if (!rc) rc = stream_after(s2, st, E);
         if (!rc) rc = stage_opens(C[0], s2);

@@ -17,6 +17,7 @@
 
 #include <mutex>
 #include <stdlib.h>
+#include <math.h>
 
 namespace {
 
@@ -31,7 +32,8 @@ constexpr u8 WEAK = 1;
 struct CannyWs {
     u8* has_weak;   // per tile: the tile holds WEAK pixels
     u32* again;     // set when a tile of another workgroup's region has to be revisited
-    u8* pending;    // per tile, or nullptr: tiles of other regions that have to be revisited (instead of `again`)
+    u8* pending;    // per tile, or nullptr: receives the tiles of other regions that have to be revisited
+    const u8* pending_in;  // per tile: the marks a seed_pending launch starts from (may be the same array as `pending`)
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -535,8 +537,11 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
                                                            int rt_x, int rt_y, int regions_x, int regions_y,
-                                                           CannyWs W, PointSink sink, int seed_pending)
+                                                           CannyWs W, PointSink sink, int seed_pending, int round_no)
 {
+    // Launch `round_no` of a sequence over the regions of huge images: nothing is left to do when the
+    // launch before it did not ask for another one (it would have raised *again to round_no).
+    if (round_no > 0 && *(volatile const u32*)W.again < (u32)round_no) return;
     __shared__ u16 s_list[2][HT_MAX_TILES];
     __shared__ u32 s_inq[HT_MAX_TILES / 32];
     __shared__ u32 s_flag[HT_MAX_TILES / 32];
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
         if (W.has_weak[gt]) {
             atomicOr(&s_flag[t >> 5], 1u << (t & 31));
             // seed_pending: only the tiles an earlier launch left marked start on the list
-            if (!seed_pending || W.pending[gt]) {
+            if (!seed_pending || W.pending_in[gt]) {
                 const u32 pos = atomicAdd(&s_cnt[0], 1u);
                 s_list[0][pos] = (u16)t;
             }
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
                     } else if (W.has_weak[((size_t)b * tiles_y + gty) * tiles_x + gtx]) {
                         // belongs to another workgroup's region: left to a later launch
                         if (W.pending) W.pending[((size_t)b * tiles_y + gty) * tiles_x + gtx] = 1;
-                        else atomicExch(W.again, 1u);
+                        if (round_no >= 0) atomicMax(W.again, (u32)round_no + 1u);
                     }
                 }
             }
@@ -724,16 +729,14 @@ __global__ __launch_bounds__(256) void k_hyst_final(Plane dst, int w, int h, int
     }
 }
 
-std::mutex g_pin_mu;
-u32* g_pinned = nullptr;  // small pinned host buffer for convergence read-backs
-
 }  // namespace
 
 size_t canny_ws_bytes(int w, int h, int batch)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     size_t ntiles = (size_t)cdiv(w, TW) * cdiv(h, TH) * batch;
-    return 2 * align_up(ntiles, 256) + 512;
+    // per tile: "holds WEAK pixels" and two sets of "revisit" marks (written / read by alternate launches); one counter
+    return 3 * align_up(ntiles, 256) + 512;
 }
 
 // Enqueues the whole detector.  Images of up to HT_MAX_TILES tiles (e.g. 4K) are
@@ -752,8 +755,9 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     CannyWs W;
     W.has_weak = (u8*)ws;
     W.pending = nullptr;
+    W.pending_in = nullptr;
     u8* const pending = (u8*)ws + align_up(ntiles, 256);  // directly behind has_weak: one memset clears both
-    W.again = (u32*)((u8*)ws + 2 * align_up(ntiles, 256));
+    W.again = (u32*)((u8*)ws + 3 * align_up(ntiles, 256));
     // Few images of at most HT_MAX_TILES tiles: one workgroup per image would leave the chip idle, so a
     // first launch works on small regions side by side and marks the tiles across region borders that
     // would have to be revisited; a second launch (one workgroup per image, started from the marked
@@ -811,11 +815,12 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         const int rx = cdiv(tiles_x, small_side), ry = cdiv(tiles_y, small_side);
         CannyWs W1 = W;
         W1.pending = pending;
+        W1.pending_in = pending;
         hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)(rx * ry * batch)), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
-                           tiles_y, small_side, small_side, rx, ry, W1, sink, 0);
+                           tiles_y, small_side, small_side, rx, ry, W1, sink, 0, -1);
         IPA_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)batch), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
-                           tiles_y, tiles_x, tiles_y, 1, 1, W1, sink, 1);
+                           tiles_y, tiles_x, tiles_y, 1, 1, W1, sink, 1, -1);
         IPA_LAUNCH_CHECK();
         const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
         hipLaunchKernelGGL(k_hyst_final, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles,
@@ -841,26 +846,34 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     const long long blocks = (long long)regions_x * regions_y * batch;
     IPA_REQUIRE(blocks < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many regions");
     const bool multi = regions_x * regions_y > 1;
-    for (int guard = 0; guard < 100000; guard++) {
-        if (multi) IPA_HIP(hipMemsetAsync(W.again, 0, 4, st));
+    // Several regions per image: launch r starts from the tiles launch r-1 marked across region borders
+    // (launch 0 from every tile with WEAK pixels) and marks the tiles it changes across borders in turn;
+    // the two sets of marks alternate.  Launches are queued four at a time -- one that has nothing to
+    // do returns at once -- and the host reads the counter once per group.
+    u8* const pend[2] = {pending, pending + align_up(ntiles, 256)};
+    if (multi) IPA_HIP(hipMemsetAsync(W.again, 0, 16, st));
+    for (int r = 0; r < 100000; r++) {
+        CannyWs Wr = W;
+        if (multi) {
+            Wr.pending = pend[r & 1];
+            Wr.pending_in = pend[(r + 1) & 1];
+            IPA_HIP(hipMemsetAsync(pend[r & 1], 0, align_up(ntiles, 256), st));
+        }
+        const int seed = multi && r > 0 ? 1 : 0, rn = multi ? r : -1;
         // few workgroups (small batches, single images): twice the waves per workgroup
         if (blocks < 1024)
             hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
-                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink, 0);
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, seed, rn);
         else
             hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
-                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink, 0);
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, seed, rn);
         IPA_LAUNCH_CHECK();
         if (!multi) break;
-        u32 again;
-        {
-            std::lock_guard<std::mutex> lk(g_pin_mu);
-            if (!g_pinned) IPA_HIP(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
-            IPA_HIP(hipMemcpyAsync(g_pinned, W.again, 4, hipMemcpyDeviceToHost, st));
-            IPA_HIP(hipStreamSynchronize(st));
-            again = g_pinned[0];
-        }
-        if (!again) break;
+        if ((r & 3) != 3) continue;
+        u32 again = 0;  // (pageable destination: the runtime stages the copy, nothing is allocated here)
+        IPA_HIP(hipMemcpyAsync(&again, W.again, 4, hipMemcpyDeviceToHost, st));
+        IPA_HIP(hipStreamSynchronize(st));
+        if (again <= (u32)r) break;  // launch r did not ask for launch r + 1
     }
     const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
     hipLaunchKernelGGL(k_hyst_final, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles,

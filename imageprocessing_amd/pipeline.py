@@ -22,6 +22,20 @@ from . import _native, cv2api
 from ._device import DevImage, check, error, stream_ptr, upload, workspace
 
 
+def set_option(name: str, value: int) -> None:
+    """Schedule switch of the fused pass for the calls that follow ("pipeline_chunks", "overlap",
+    "phased", "head_start_ticks"; see include/ipamd.h).  Results never depend on them."""
+    check(_native.lib().ipa_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    import ctypes as C
+
+    v = C.c_int()
+    check(_native.lib().ipa_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
 @dataclasses.dataclass
 class FrontEndResult:
     gray: object

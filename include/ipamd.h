@@ -62,6 +62,19 @@ const char* ipa_last_error(void);
 /* Smallest multiple of 256 that is >= row_bytes: the pitch the library prefers. */
 size_t ipa_pitch_for(size_t row_bytes);
 
+/* Run-time switches of the fused front-end's schedule (no reference counterpart: cv2 exposes only
+ * cv2.setNumThreads, which the reference never calls).  Options, with the environment variable that
+ * gives the default in brackets:
+ *   "pipeline_chunks"  [IPA_PIPELINE]    -1 = by batch size (default); 0 or 1 = one chain on the
+ *                                        caller's stream; n <= 8 = that many chunks whose stages
+ *                                        overlap on helper streams
+ *   "overlap"          [IPA_OVERLAP]     0 = a single chain keeps the opens on the caller's stream
+ *   "phased"           [IPA_PHASED]      0 = chunks alternate between two streams also with a Hough stage
+ *   "head_start_ticks" [IPA_HEAD_START]  head start of a resident vote kernel in 10 ns ticks
+ * Results do not depend on any of them.  Settings apply to the calls that follow, from any thread. */
+int ipa_set_option(const char* name, int value);
+int ipa_get_option(const char* name, int* value);
+
 /* Optional per-stage timing of the fused front-end (no reference counterpart:
  * the reference only reports whole-request wall time, umlClassdiagram.py:1096,
  * 1145-1151).  When enabled, HIP events are recorded on the caller's stream around
@@ -212,7 +225,8 @@ int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
  * at most 4096 tiles of 128x32 pixels (one workgroup per image; for batches of up
  * to 48 images a first launch works on small regions side by side and a second one
  * finishes what crosses their borders); larger images are resolved region by
- * region and the call then synchronises `stream` once per convergence check. */
+ * region in launches queued four at a time, and the call then synchronises `stream`
+ * once per group to learn whether another group is needed. */
 size_t ipa_canny_workspace_bytes(int width, int height, int batch);
 int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
                  uint8_t* dst, size_t dst_pitch, size_t dst_stride,
@@ -321,6 +335,9 @@ int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t src_stride
  * the binarisation of the next, the opens beside Canny); all of it is joined back into
  * `stream` before the call returns, so the caller sees ordinary stream order. */
 size_t ipa_front_end_workspace_bytes(int width, int height, int batch, int max_points);
+/* Number of chunks ipa_front_end_u8 would cut this batch into with the current options (1 = one
+ * chain; 0 for an empty batch).  Diagnostics: tests use it to know which schedule they exercised. */
+int ipa_front_end_chunks(int width, int height, int batch);
 int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
                      uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,
                      size_t plane_pitch, size_t plane_stride,

@@ -415,6 +415,7 @@ def threads_case(rng):
             errors.append(f"{type(ex).__name__}: {ex}")
 
     th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    ipa.set_option("pipeline_chunks", int(rng.choice([-1, 2, 3])))
     for x in th:
         x.start()
     for x in th:
@@ -479,8 +480,14 @@ def main():
         blur, hough = bool(rng.random() < 0.3), bool(rng.random() < 0.7)
         edges = hough or bool(rng.random() < 0.7)
         imgs = diagram(rng, n, h, w)
-        tag = f"case {seed0 + c}: n={n} {w}x{h} t={t} v={vl} h={hl} it={it} canny=({lo:.1f},{hi:.1f}) blur={blur} hough={hough} edges={edges}"
+        # schedule of the fused pass: one chain, or 2..8 chunks (phased or staggered) whatever the size
+        chunks = int(rng.choice([-1, 1, 2, 3, 4, 8])) if n >= 2 else -1
+        phased = int(rng.random() < 0.7)
+        tag = (f"case {seed0 + c}: n={n} {w}x{h} t={t} v={vl} h={hl} it={it} canny=({lo:.1f},{hi:.1f}) blur={blur} hough={hough} "
+               f"edges={edges} chunks={chunks} phased={phased}")
         try:
+            ipa.set_option("pipeline_chunks", chunks)
+            ipa.set_option("phased", phased)
             r = ipa.front_end_batch(imgs, thresh_val=t, vert_len=vl, horiz_len=hl, iterations=it, canny=(lo, hi),
                                     blur=blur, hough=hough, edges=edges)
             acc = r.accum.cpu().numpy() if r.accum is not None else None

@@ -1,0 +1,121 @@
+"""BASELINE config 4 at size: one 16384x16384 "scanned whiteboard" raster (seed 9000, paper noise +-6,
+illumination gradient), line kernels of 101 pixels with iterations 1 and 2, Canny, the Hough
+accumulator and the HoughLines list, plus the Otsu / adaptive / blur prefix of
+NewVersion2/img2UML.py:26-35 on the same raster.  This size takes the paths small images never reach:
+hysteresis region by region with a convergence check per group of launches, the sliced vote with one
+angle per workgroup, the LDS-tile bit-plane kernel for the 201-pixel horizontal line.
+Expected values: origin `restatement` (oracle/frontref.c)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontref as fr
+from tests.conftest import GOLDEN  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+S = 16384
+
+
+@pytest.fixture(scope="module")
+def board():
+    from imageprocessing_amd.synth import synth_diagram
+
+    bgr = synth_diagram(9000, S, S, noise=6, gradient=True)
+    gray = fr.bgr2gray(bgr)
+    return bgr, gray
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("it", [2, 1])
+def test_config4_full_front_end(it, board):
+    import imageprocessing_amd as ipa
+
+    bgr, gray = board
+    t0 = time.perf_counter()
+    res = ipa.front_end(bgr, thresh_val=128, vert_len=101, horiz_len=101, iterations=it, hough_threshold=3000)
+    torch.cuda.synchronize()
+    print(f"16k front end it={it}: {time.perf_counter() - t0:.2f} s host to host")
+    th = fr.threshold(gray, 128, 255, 1)[1]
+    assert np.array_equal(res.gray, gray)
+    assert np.array_equal(res.thresh, th)
+    assert np.array_equal(res.vlines, fr.morphology_ex(th, 2, (1, 101), it))
+    assert np.array_equal(res.hlines, fr.morphology_ex(th, 2, (101, 1), it))
+    assert int((res.hlines > 0).sum()) > 10000 and int((res.vlines > 0).sum()) > 10000
+    if it == 2:
+        e = fr.canny(gray, 50, 150)
+        assert np.array_equal(res.edges, e)
+        acc = fr.hough_accum(e, 1.0, np.pi / 180)
+        assert np.array_equal(res.accum.cpu().numpy(), acc)
+        want = fr.hough_peaks(acc, 1.0, np.pi / 180, 3000)
+        assert want is not None and len(want) > 10
+        assert np.array_equal(res.lines, want)
+
+
+@pytest.mark.timeout(900)
+def test_config4_otsu_adaptive_blur_close_open(board):
+    # NewVersion2/img2UML.py:26-35 and "New Version/textDetection.py":23 on the noisy page: Otsu sees a
+    # histogram with no dominant value, the adaptive thresholds a non-constant mean
+    import imageprocessing_amd as cv2
+
+    _, gray = board
+    g = torch.from_numpy(gray).cuda()
+    r, d = cv2.threshold(g, 0, 255, cv2.THRESH_BINARY + cv2.THRESH_OTSU)
+    r0, d0 = fr.threshold(gray, 0, 255, 8)
+    assert r == r0 and 40 < r0 < 230
+    assert np.array_equal(d.cpu().numpy(), d0)
+    blur = cv2.GaussianBlur(g, (5, 5), 0)
+    b0 = fr.gaussian_blur(gray, (5, 5), 0)
+    assert np.array_equal(blur.cpu().numpy(), b0)
+    for block in (11, 31):
+        a = cv2.adaptiveThreshold(blur, 255, cv2.ADAPTIVE_THRESH_GAUSSIAN_C, cv2.THRESH_BINARY, block, 2)
+        a0 = fr.adaptive_threshold(b0, 255, 1, 0, block, 2)
+        assert np.array_equal(a.cpu().numpy(), a0), block
+        if block == 11:
+            k = np.ones((3, 3), np.uint8)
+            c = cv2.morphologyEx(a, cv2.MORPH_CLOSE, k, iterations=2)
+            o = cv2.morphologyEx(c, cv2.MORPH_OPEN, k, iterations=1)
+            c0 = fr.morphology_ex(a0, 3, (3, 3), 2)
+            assert np.array_equal(c.cpu().numpy(), c0)
+            assert np.array_equal(o.cpu().numpy(), fr.morphology_ex(c0, 2, (3, 3), 1))
+    # gray-level (not two-valued) morphology with the long kernels
+    for ks in ((101, 1), (1, 101)):
+        got = cv2.morphologyEx(g, cv2.MORPH_OPEN, np.ones((ks[1], ks[0]), np.uint8))
+        assert np.array_equal(got.cpu().numpy(), fr.morphology_ex(gray, 2, ks, 1)), ks
+
+
+def _weak_serpentine(h, w):
+    """One connected low-contrast curve (weak only) that sweeps the image row band by row band."""
+    g = np.full((h, w), 200, np.uint8)
+    k, y = 0, 40
+    while y + 80 < h:
+        g[y:y + 20, 30:w - 30] = 180
+        if y + 60 + 20 + 80 < h + 60:
+            xs = slice(w - 50, w - 30) if k % 2 == 0 else slice(30, 50)
+            g[y:y + 80, xs] = 180
+        y += 60
+        k += 1
+    return g
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("h,w", [(4352, 4352), (2100, 8400)])
+def test_canny_hysteresis_over_many_regions_of_a_huge_image(h, w):
+    # more than 4096 tiles of 128x32: hysteresis runs region by region (16x16 tiles), several launches
+    # queued at a time; a weak curve seeded at one end crosses every region border many times and needs
+    # dozens of launches to be followed to its other end
+    import imageprocessing_amd as cv2
+
+    assert (-(-w // 128)) * (-(-h // 32)) > 4096
+    g = _weak_serpentine(h, w)
+    assert fr.canny(g, 50, 150).sum() == 0
+    g[38:44, 28:34] = 0  # the only strong pixels
+    want = fr.canny(g, 50, 150)
+    assert want.sum() > 255 * 100000
+    assert np.array_equal(cv2.Canny(g, 50, 150), want)
+    # the same through the fused pass (gray as BGR), and upside down
+    pad = np.stack([g[::-1, ::-1]] * 3, axis=-1)
+    r = cv2.front_end(np.ascontiguousarray(pad), hough=False)
+    assert np.array_equal(r.edges, fr.canny(np.ascontiguousarray(g[::-1, ::-1]), 50, 150))

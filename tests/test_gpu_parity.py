@@ -464,13 +464,25 @@ def test_front_end_batch_matches_single():
         _check_front_end(single, batch[i], 128, 15, 15, 2, 50, 150, False)
 
 
-@pytest.mark.parametrize("n,hough", [(70, True), (131, True), (70, False)])
-def test_front_end_large_batch_runs_in_chunks(n, hough):
-    # batches of 64 images and more are cut into chunks of at least 32 that overlap on two streams
-    # (with a Hough stage: the vote of one chunk beside the binarisation of the next)
+@pytest.mark.parametrize("n,hough,chunks,phased", [(70, True, 2, 1), (131, True, 4, 1), (70, False, 2, 1), (37, True, 8, 1),
+                                                   (45, True, 3, 0)])
+def test_front_end_large_batch_runs_in_chunks(n, hough, chunks, phased):
+    # the chunked schedules of large batches (by default from about 1.5 gigapixels on), forced here on
+    # small images: chunks of uneven size whose stages overlap on two helper streams -- with a Hough
+    # stage the vote of one chunk as a resident grid beside the binarisation of the next ("phased"),
+    # otherwise chunks alternating between two streams
     h, w = 72, 112
     batch = np.stack([uml_like(3000 + i, h, w, noise=(3 if i % 3 == 0 else 0)) for i in range(n)])
-    res = cv2.front_end_batch(batch, thresh_val=140, hough=hough)
+    cv2.set_option("pipeline_chunks", chunks)
+    cv2.set_option("phased", phased)
+    try:
+        from imageprocessing_amd import _native
+
+        assert _native.lib().ipa_front_end_chunks(w, h, n) == chunks
+        res = cv2.front_end_batch(batch, thresh_val=140, hough=hough)
+    finally:
+        cv2.set_option("pipeline_chunks", -1)
+        cv2.set_option("phased", 1)
     for i in range(n):
         single = cv2.FrontEndResult(res.gray[i], res.thresh[i], res.vlines[i], res.hlines[i], res.edges[i],
                                     res.accum[i] if hough else None)
@@ -980,9 +992,9 @@ def test_reversed_and_strided_numpy_views():
 
 
 def test_fused_pass_from_several_host_threads():
-    # the library is re-entrant per (device, stream): chunked fused passes (64 images or more, helper
-    # streams of the library involved) issued at the same time from three host threads on streams of
-    # their own
+    # the library is re-entrant per (device, stream): chunked fused passes (three chunks each, forced; helper
+    # streams of the library involved, one pair per caller's stream) issued at the same time from three
+    # host threads on streams of their own
     import threading
 
     from imageprocessing_amd.synth import synth_batch
@@ -1001,13 +1013,17 @@ def test_fused_pass_from_several_host_threads():
             errors.append(ex)
 
     threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
+    cv2.set_option("pipeline_chunks", 3)
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    finally:
+        cv2.set_option("pipeline_chunks", -1)
     assert not errors, errors
     for t in range(3):
-        for b in (0, 31, 32, n - 1):
+        for b in (0, 21, 22, 43, 44, n - 1):
             want = fr.front_end(batches[t][b], t=100 + 20 * t)
             for got, exp in zip(results[t], want):
                 assert np.array_equal(got[b], exp), (t, b)
