@@ -51,6 +51,8 @@ SIGNATURES = {
     "ipa_binary_check_u8": (_i, [_vp, _sz, _sz, _i, _i, _i, _vp, _vp]),
     "ipa_canny_workspace_bytes": (_sz, [_i, _i, _i]),
     "ipa_canny_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _d, _d, _vp, _sz, _vp]),
+    "ipa_canny_static_max_bytes": (_sz, []),
+    "ipa_canny_static_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _d, _d, _vp]),
     "ipa_hough_dims": (_i, [_i, _i, _d, _d, C.POINTER(_i), C.POINTER(_i)]),
     "ipa_hough_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ipa_hough_segments": (_i, [_i]),

@@ -907,3 +907,55 @@ IPA_EXPORT int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_str
     PointSink none = {nullptr, 0, 0, nullptr};
     return run_canny(s, d, width, height, batch, low, high, ws, ws_bytes, none, (hipStream_t)stream);
 }
+
+// ---- Canny for callers that cannot allocate -------------------------------------------------
+// Same detector, same kernels; the per-tile scratch lives in a device array of the library
+// instead of a caller's workspace.  Every GPU holds its own copy of the array at its own
+// address, looked up once per device.
+constexpr size_t CANNY_STATIC_BYTES = IPA_CANNY_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[CANNY_STATIC_BYTES];
+
+namespace {
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[64] = {};
+
+// Device address of `scratch` on the current device (nullptr + error text on failure).
+void* static_scratch_ptr()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        ipa_set_error("Canny (static scratch): no current device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            ipa_set_error("hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    return g_scratch_ptr[dev];
+}
+}  // namespace
+
+IPA_EXPORT size_t ipa_canny_static_max_bytes(void) { return CANNY_STATIC_BYTES; }
+
+IPA_EXPORT int ipa_canny_static_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
+                                   size_t dst_stride, int width, int height, int batch, double threshold1,
+                                   double threshold2, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK;
+    const size_t need = canny_ws_bytes(width, height, batch);
+    IPA_REQUIRE(need <= CANNY_STATIC_BYTES, IPA_ERR_WORKSPACE,
+                "Canny (static scratch): %d x %d x %d images need %zu bytes of scratch, the built-in array holds %zu "
+                "(use ipa_canny_u8 with a workspace)",
+                width, height, batch, need, CANNY_STATIC_BYTES);
+    void* ws = static_scratch_ptr();
+    if (!ws) return IPA_ERR_HIP;
+    return ipa_canny_u8(src, src_pitch, src_stride, dst, dst_pitch, dst_stride, width, height, batch, threshold1, threshold2,
+                        ws, CANNY_STATIC_BYTES, stream);
+}

@@ -234,6 +234,24 @@ int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
                  double threshold1, double threshold2,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* ipa_canny_u8 for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference (cv2.Canny allocates its own buffers on every call).  The per-tile
+ * scratch of the detector lives in a device array inside the library,
+ * IPA_CANNY_STATIC_SCRATCH_BYTES per GPU, held until the process ends; the call makes no
+ * hipMalloc / hipFree and takes no workspace.  Same kernels and results as ipa_canny_u8.
+ * Batches that need more scratch than the array holds (ipa_canny_workspace_bytes() >
+ * ipa_canny_static_max_bytes(): more than about 174 000 tiles of 128x32 pixels, e.g. 85
+ * images of 3840x2160) are refused with IPA_ERR_WORKSPACE.  The device of `stream` must be
+ * the current device.  All calls on one GPU share the array: calls that overlap in time on
+ * one GPU (different streams or threads) race and must be serialised by the caller. */
+#define IPA_CANNY_STATIC_SCRATCH_BYTES ((size_t)512 * 1024)
+size_t ipa_canny_static_max_bytes(void);
+int ipa_canny_static_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                        uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                        int width, int height, int batch,
+                        double threshold1, double threshold2, void* stream);
+
 /* ---- standard Hough transform ------------------------------------------ */
 
 /* Accumulator geometry of cv2.HoughLines(img, rho, theta, threshold)
