@@ -6,9 +6,13 @@ Hough accumulator + peaks) on synthetic UML-like rasters.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size 4k|1080p|16k] [--no-cpu]
 
 N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``:
-one process per GPU, every rank runs the same per-GPU batch of its own images (weak
-scaling, per-image sharding, no data-path collective); the only communication is the
-barrier and the max-reduce of the elapsed time.
+one process per GPU.  By default the N > 1 workload is a FIXED total of 4096 4K diagrams (seeds
+4000..8095) split by image index over the ranks (``sharding.shard_range``; 2048 / 1024 / 512 images
+per GPU at N = 2 / 4 / 8), each rank running the whole front-end on its block; ``--weak`` gives every
+rank 1024 images of its own instead.  No collective touches the data path: the only communication
+is the barrier, the max-reduce of the elapsed time and, outside the timed region, the host gather of
+per-image checksums to rank 0 (``sharding.gather_to_rank0``), which checks a sample of them against
+its own single-GPU run of the same seeds.  N = 1 runs 1024 diagrams (seeds 2000..3023) on one GPU.
 
 A step = one pass of ``ipa_front_end_u8`` + ``ipa_hough_peaks_i32`` over a batch that is
 already resident in HBM.  The JSON line also carries the roofline of the dominant kernel
@@ -146,6 +150,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="backend of the barrier / max-time reduction (gloo: rehearsal of the N>1 path without N GPUs)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--weak", action="store_true", help="N > 1: --batch images per rank instead of a fixed total split over the ranks")
+    ap.add_argument("--total", type=int, default=4096, help="N > 1 without --weak: images in total (split by index over the ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +168,17 @@ def main():
     kw = {"noise": 6, "gradient": True} if args.size == "16k" else {}
     line_len = 101 if args.size == "16k" else 15
     seed0 = {"1080p": 1000, "4k": 2000, "16k": 9000}[args.size] + rank * batch
+    # N > 1: a fixed total split by image index over the ranks (strong scaling), unless --weak
+    sharded = world > 1 and not args.weak and args.size == "4k" and not args.batch
+    total = world * batch
+    shard_lo = rank * batch
+    if sharded:
+        from imageprocessing_amd.sharding import shard_range
+
+        total = args.total
+        shard_lo, shard_hi = shard_range(total, rank, world)
+        batch = shard_hi - shard_lo
+        seed0 = 4000 + shard_lo
 
     workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
     gen = HostGenerator(batch, h, w, workers)  # forks its workers before the GPU is touched
@@ -236,12 +253,59 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-image checksums of every output (sums of the five planes, of the accumulator, and the number of edge
+    # pixels), gathered on the host of rank 0 outside the timed region
+    def checksums(fe_, n):
+        rows = []
+        for i0 in range(0, n, 16):
+            i1 = min(i0 + 16, n)
+            cols = [fe_.plane(k).t[i0:i1, :h, :w].sum(dim=(1, 2), dtype=torch.int64) for k in range(5)]
+            cols.append(fe_.accum[i0:i1].sum(dim=(1, 2), dtype=torch.int64))
+            cols.append(fe_.point_counts[i0:i1].to(torch.int64))
+            rows.append(torch.stack(cols, dim=1))
+        return torch.cat(rows).cpu().numpy() if rows else np.zeros((0, 7), np.int64)
+
+    gather_note = None
+    sums_bad = 0
+    if world > 1 and sharded:
+        from imageprocessing_amd.sharding import gather_to_rank0
+
+        mine = checksums(fe, batch)
+        host_group = None
+        try:
+            host_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else None
+            all_sums = gather_to_rank0(mine, total, rank, world, group=host_group)
+            how = "host gather (gloo, point to point)"
+        except Exception as e:  # no usable host transport: the checksums travel as one device all_gather
+            sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+            pad = torch.zeros((max(sizes), 7), dtype=torch.int64, device=dev)
+            pad[:batch] = torch.from_numpy(mine).to(dev)
+            out_t = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(out_t, pad)
+            all_sums = np.concatenate([o[:n].cpu().numpy() for o, n in zip(out_t, sizes)]) if rank == 0 else None
+            how = f"device all_gather (host gather failed: {type(e).__name__})"
+        if rank == 0:
+            # a sample of the other ranks' images, recomputed here on this GPU from the same seeds
+            from imageprocessing_amd.synth import synth_diagram
+
+            assert all_sums.shape == (total, 7)
+            ids = sorted(set(np.linspace(0, total - 1, 2 * world + 1).astype(int).tolist()))
+            one = ipa.FrontEnd(1, h, w, thresh_val=128, vert_len=line_len, horiz_len=line_len, iterations=2,
+                               canny=(50, 150), blur=args.blur, hough=True)
+            from imageprocessing_amd._device import upload
+
+            for i in ids:
+                one.run(upload(synth_diagram(4000 + i, h, w, **kw), 3))
+                sums_bad += int(not np.array_equal(checksums(one, 1)[0], all_sums[i]))
+            gather_note = (f"{total} per-image checksum rows on rank 0 by {how}; {len(ids)} images of all ranks recomputed "
+                           f"on rank 0: {'all equal' if sums_bad == 0 else str(sums_bad) + ' DIFFER'}")
+
     # correctness spot check outside the timed region (oracle = checker only)
     check_note = "skipped"
+    bad = 0
     if args.check > 0:
         from oracle import frontref as fr
 
-        bad = 0
         ids = sorted(set(np.linspace(0, batch - 1, min(args.check, batch)).astype(int).tolist()))
         for i in ids:
             src = bgr.t[i, :h, : w * 3].cpu().numpy().reshape(h, w, 3)
@@ -257,6 +321,12 @@ def main():
         check_note = f"{len(ids)} images x 6 outputs bit-exact vs oracle" if bad == 0 else f"{bad} MISMATCHING outputs"
         if bad:
             print(f"bench.py: rank {rank}: parity check failed: {check_note}", file=sys.stderr)
+    bad += sums_bad
+    bad_all = bad
+    if world > 1:  # rank 0 reports the checks of every rank
+        tb = torch.tensor([bad], dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(tb)
+        bad_all = int(tb.item())
 
     if rank == 0:
         npix = float(batch) * h * w
@@ -315,7 +385,7 @@ def main():
                 cpu = cpu_baseline(h, w, kw)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cpu = {"error": str(e)}
-        value = npix * world * args.steps / elapsed / 1e6
+        value = float(total) * h * w * args.steps / elapsed / 1e6
         whole = (8.0 * npix + acc_bytes * batch) * args.steps / elapsed / 1e9
         out = {
             "metric": "megapixels/sec through binarize+morph+Canny+Hough",
@@ -326,15 +396,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"{batch} x {w}x{h} synthetic UML diagrams per GPU, full front-end "
+            "config": {"workload": (f"{total} x {w}x{h} synthetic UML diagrams in total, split by image index over {world} GPUs "
+                                    f"({batch} on rank 0), full front-end " if sharded else
+                                    f"{batch} x {w}x{h} synthetic UML diagrams per GPU, full front-end ") +
                                    f"(gray, threshold 128 INV, open 1x{line_len}/{line_len}x1 it=2, "
                                    f"{'GaussianBlur 5x5, ' if args.blur else ''}Canny 50/150, Hough 1/pi/180 + peaks>"
                                    f"{args.hough_threshold})",
-                       "images_per_gpu": batch, "width": w, "height": h, "sharding": "per-image, no collective"},
+                       "images_per_gpu": batch, "images_total": total, "width": w, "height": h,
+                       "sharding": "per-image, no collective"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "pipeline_algorithmic_GBps_per_gpu": round(whole, 1),
@@ -342,11 +415,15 @@ def main():
             "stages": stages,
             "stage_timing": f"HIP events, separate pass of {prof_steps} steps with the stages serialised (the timed steps overlap stages)",
             "parity_check": check_note,
+            "parity_ok": (bad_all == 0) if (args.check > 0 or sharded) else None,
+            "shard_gather": gather_note,
             "gen_seconds": round(t_gen, 1),
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if bad_all:
+        sys.exit(3)  # a throughput line next to wrong results must not read as a pass
 
 
 if __name__ == "__main__":

@@ -13,6 +13,6 @@ from .cv2api import hough_accumulator, hough_dims, hough_peaks, hough_peaks_batc
 from .pipeline import (FrontEnd, FrontEndResult, edges_and_lines, erase_rects, front_end, front_end_batch,  # noqa: F401
                        get_option, get_segments, rebinarize, segments_batch, set_option)
 from .batching import ParsedImage, decode_bgr, decode_many, group_by_shape, process_files, process_images  # noqa: F401
-from .sharding import gather_to_rank0, shard_range, shard_round_robin  # noqa: F401
+from .sharding import front_end_sharded, gather_to_rank0, plan_shards, shard_range, shard_round_robin  # noqa: F401
 
 __version__ = "0.1.0"

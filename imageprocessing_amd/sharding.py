@@ -69,3 +69,88 @@ def plane_checksums(planes: np.ndarray) -> np.ndarray:
     flat = planes.reshape(n, -1).astype(np.uint64)
     idx = (np.arange(flat.shape[1], dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) & np.uint64(0xFFFFFFFF)
     return (flat * idx[None, :]).sum(axis=1, dtype=np.uint64)
+
+
+def plan_shards(n_items: int, n_devices: int, max_batch: int = 0) -> List[Tuple[int, int, int]]:
+    """Work list of the single-process dispatcher: (device slot, lo, hi) triples that cover
+    [0, n_items) once, in image order.  Every device slot gets the contiguous block of
+    ``shard_range``; blocks longer than ``max_batch`` (0 = no limit) are cut into device batches of
+    at most that many images, so that a device's planes and workspace stay within its memory."""
+    if n_devices <= 0 or n_items < 0 or max_batch < 0:
+        raise ValueError("bad shard arguments")
+    work = []
+    for d in range(n_devices):
+        lo, hi = shard_range(n_items, d, n_devices)
+        step = max_batch if max_batch else max(hi - lo, 1)
+        for a in range(lo, hi, step):
+            work.append((d, a, min(a + step, hi)))
+    return work
+
+
+def front_end_sharded(images, devices: Sequence[int] = None, max_batch: int = 256, **kw):
+    """The fused front-end of a batch uint8[N,H,W,3] (host array) over several GPUs from ONE process:
+    the batched replacement of the per-file loop of receiveFile.py:22 when one process owns the node.
+
+    Images are split by index (``plan_shards``); every device slot has a host thread, a stream and
+    page-locked staging of its own and runs ``front_end_batch`` on its blocks; the per-image results
+    come back as host arrays concatenated in image order (host gather, no collective).  ``devices``
+    defaults to all visible GPUs; a device may be listed more than once (several streams on it).
+    Keyword arguments are those of ``front_end_batch``; returns a ``FrontEndResult`` of numpy arrays
+    (``accum`` as a host array too)."""
+    import threading
+
+    import torch
+
+    from . import pipeline
+
+    imgs = np.asarray(images)
+    if imgs.ndim != 4 or imgs.shape[3] != 3 or imgs.dtype != np.uint8:
+        raise ValueError("front_end_sharded: uint8[N,H,W,3] expected")
+    if devices is None:
+        devices = list(range(torch.cuda.device_count()))
+    if not devices:
+        raise RuntimeError("front_end_sharded: no GPU visible (there is no CPU path)")
+    n, h, w = int(imgs.shape[0]), int(imgs.shape[1]), int(imgs.shape[2])
+    work = plan_shards(n, len(devices), max_batch)
+    hough = kw.get("hough", True)
+    edges = kw.get("edges", True) or hough
+    planes = [np.empty((n, h, w), np.uint8) if (k < 4 or edges) else None for k in range(5)]
+    accum = [None] * n
+    lines = [None] * n
+    errors: List[BaseException] = []
+
+    def run_slot(slot: int):
+        try:
+            dev = torch.device("cuda", int(devices[slot]))
+            with torch.cuda.device(dev):
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    for d, lo, hi in work:
+                        if d != slot or hi <= lo:
+                            continue
+                        pin = torch.empty((hi - lo, h, w, 3), dtype=torch.uint8, pin_memory=True)
+                        pin.numpy()[...] = imgs[lo:hi]
+                        res = pipeline.front_end_batch(pin.to(dev, non_blocking=True), **kw)
+                        for k, pl in enumerate((res.gray, res.thresh, res.vlines, res.hlines, res.edges)):
+                            if pl is not None:
+                                planes[k][lo:hi] = pl.cpu().numpy()
+                        if res.accum is not None:
+                            a = res.accum.cpu().numpy()
+                            for i in range(lo, hi):
+                                accum[i] = a[i - lo]
+                        if res.lines is not None:
+                            lines[lo:hi] = res.lines
+                    st.synchronize()
+        except BaseException as ex:  # re-raised by the caller's thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=run_slot, args=(s,)) for s in range(len(devices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    acc = np.stack(accum) if (hough and n) else None
+    return pipeline.FrontEndResult(planes[0], planes[1], planes[2], planes[3], planes[4], accum=acc,
+                                   lines=lines if kw.get("hough_threshold") is not None and hough else None)

@@ -1029,6 +1029,25 @@ def test_fused_pass_from_several_host_threads():
                 assert np.array_equal(got[b], exp), (t, b)
 
 
+def test_front_end_sharded_single_process_dispatcher():
+    # one process, several device slots (here: three streams on the one visible GPU, and the default = all
+    # visible GPUs): per-image split, host gather in image order -- the replacement of receiveFile.py:22
+    n, h, w = 11, 120, 200
+    batch = np.stack([uml_like(6100 + i, h, w, noise=(2 if i % 4 == 1 else 0)) for i in range(n)])
+    for devices, mb in (([0, 0, 0], 2), (None, 256)):
+        r = cv2.front_end_sharded(batch, devices=devices, max_batch=mb, thresh_val=150, hough_threshold=50)
+        assert r.gray.shape == (n, h, w) and r.accum.shape[0] == n and len(r.lines) == n
+        for i in range(n):
+            single = cv2.FrontEndResult(r.gray[i], r.thresh[i], r.vlines[i], r.hlines[i], r.edges[i], torch.from_numpy(r.accum[i]))
+            _check_front_end(single, batch[i], 150, 15, 15, 2, 50, 150, False)
+            want = fr.hough_lines(r.edges[i], 1, np.pi / 180, 50)
+            assert (r.lines[i] is None) == (want is None)
+            if want is not None:
+                assert np.array_equal(r.lines[i], want)
+    r = cv2.front_end_sharded(batch[:3], devices=[0, 0], hough=False, edges=False)
+    assert r.edges is None and r.accum is None and np.array_equal(r.gray[2], fr.bgr2gray(batch[2]))
+
+
 def test_c_abi_from_a_plain_c_program():
     # tests/c_abi/front_end_c: hipMalloc + ipa_front_end_u8 + hipMemcpy, no Python or torch in the process;
     # it compares all five planes and the accumulator with the CPU restatement itself

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from imageprocessing_amd.sharding import gather_to_rank0, plane_checksums, shard_range, shard_round_robin  # noqa: E402
+from imageprocessing_amd.sharding import (gather_to_rank0, plan_shards, plane_checksums, shard_range,  # noqa: E402
+                                          shard_round_robin)
 
 
 @pytest.mark.parametrize("n,world", [(0, 1), (1, 1), (1, 8), (7, 2), (8, 8), (4096, 8), (1024, 3), (5, 4)])
@@ -35,6 +36,21 @@ def test_shard_round_robin_covers_everything():
     assert shard_round_robin(3, 3, 4).tolist() == []
     with pytest.raises(ValueError):
         shard_range(5, 2, 2)
+
+
+@pytest.mark.parametrize("n,devs,mb", [(0, 1, 0), (1, 8, 0), (4096, 8, 256), (4096, 8, 0), (1000, 3, 128), (5, 4, 1), (7, 2, 3)])
+def test_plan_shards_covers_every_image_once_in_order(n, devs, mb):
+    # index logic of the single-process multi-GPU dispatcher (front_end_sharded)
+    work = plan_shards(n, devs, mb)
+    covered = [i for _, lo, hi in work for i in range(lo, hi)]
+    assert covered == list(range(n))
+    for d, lo, hi in work:
+        a, b = shard_range(n, d, devs)
+        assert a <= lo < hi <= b and (mb == 0 or hi - lo <= mb)
+    if n >= devs:
+        assert {d for d, _, _ in work} == set(range(devs))
+    with pytest.raises(ValueError):
+        plan_shards(4, 0)
 
 
 def _free_port():
