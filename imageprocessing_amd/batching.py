@@ -30,13 +30,22 @@ class ParsedImage:
 
 
 def decode_bgr(blob) -> Optional[np.ndarray]:
-    """bytes / file-like -> uint8[H,W,3] BGR, or None when the data is no image (cv2.imdecode's None)."""
-    from PIL import Image
+    """bytes / file-like -> uint8[H,W,3] BGR, or None when the data is no image (cv2.imdecode's None).
+
+    Like cv2.imdecode(..., IMREAD_COLOR): palette and gray images are expanded, alpha is dropped, the
+    EXIF orientation is applied, and 16-bit samples are reduced to their high byte (cv2 scales 16-bit
+    files by 1/256 when it converts them to 8 bits)."""
+    from PIL import Image, ImageOps
 
     try:
         data = blob.read() if hasattr(blob, "read") else blob
         with Image.open(io.BytesIO(bytes(data))) as im:
-            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+            im = ImageOps.exif_transpose(im)
+            if im.mode.startswith("I;16") or im.mode == "I":
+                g = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)
+                rgb = np.repeat(g[:, :, None], 3, axis=2)
+            else:
+                rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
     except Exception:
         return None
     return np.ascontiguousarray(rgb[:, :, ::-1])

@@ -77,6 +77,7 @@ class FrontEnd:
             self.accum = None
             self.point_counts = None
             self.seg_max = None
+        self._unchecked = False
         self._alloc_ws()
 
     def _alloc_ws(self):
@@ -105,20 +106,33 @@ class FrontEnd:
             self.width, self.height, self.batch, self.thresh_val, self.vert_len, self.horiz_len, self.iterations,
             float(self.canny[0]), float(self.canny[1]), 1 if self.blur else 0,
             self.ws.data_ptr(), self.ws.numel(), stream_ptr()))
+        self._unchecked = self.hough and self.max_points < self.height * self.width
+
+    def check_overflow(self) -> bool:
+        """True when an image of the last ``enqueue`` had more edge pixels than ``max_points``: its
+        accumulator is incomplete (``run`` re-plans and repeats the pass by itself).  Reads the counts
+        back, i.e. waits for the pass."""
+        over = False
+        if self.hough and self.batch and self.max_points < self.height * self.width:
+            over = int(self.point_counts[: self.batch].max().item()) > self.max_points
+        self._unchecked = False
+        return over
 
     def run(self, bgr: DevImage) -> None:
         """``enqueue`` plus the overflow check of the Hough point lists (re-plans and re-runs
         once with full-size lists if an image had more edge pixels than planned for)."""
         self.enqueue(bgr)
-        if self.hough and self.batch:
-            most = int(self.point_counts[: self.batch].max().item())
-            if most > self.max_points:
-                self.max_points = self.height * self.width
-                self._alloc_ws()
-                self.enqueue(bgr)
+        if self.check_overflow():
+            self.max_points = self.height * self.width
+            self._alloc_ws()
+            self.enqueue(bgr)
+            self._unchecked = False
 
     def lines(self, threshold: int):
         """Per-image cv2.HoughLines output from the accumulators of the last run."""
+        if self._unchecked and self.check_overflow():
+            raise error("front_end: an image has more edge pixels than max_points, its accumulator is incomplete "
+                        "(use run(), or plan the FrontEnd with a larger max_points)")
         allkeys = cv2api.hough_peaks_batch(self.accum[: self.batch], int(threshold), seg_max=self.seg_max[: self.batch])
         return [cv2api.lines_from_keys(k, self.nr, 1.0, np.pi / 180) if k.size else None for k in allkeys]
 

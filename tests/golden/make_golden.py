@@ -14,8 +14,15 @@ Origins (every expected value is labelled):
 * ``cd.npz`` / ``login.npz`` -- decoded BGR pixels of images/cd.png (the
   config-0 input) and images/login.png (what lineDetection.py:5 loads); inputs
   only, ``restatement`` outputs are derived in the tests.
+* ``login.png`` + ``output_bmp_pin.npz`` -- origin ``cv2-artefact``.  output.bmp at the root of the
+  reference is ``cv2.imwrite("output.bmp", cv2.imread("images/login.png"))``
+  (NewVersion2/img2UML.py:16-17): BMP stores the BGR pixels cv2 decoded, so it pins what
+  ``cv2.imread`` / ``cv2.imdecode(IMREAD_COLOR)`` makes of that palette PNG.  The fixture keeps the
+  PNG file itself (a 15 kB data file), the SHA-256 of output.bmp's pixel array and a 96x128 crop.
 """
+import hashlib
 import os
+import shutil
 
 import numpy as np
 from PIL import Image
@@ -58,6 +65,11 @@ def main():
         a = load_bgr(f"{REF}/images/{name}.png")
         np.savez_compressed(f"{OUT}/{name}.npz", bgr=a)
         print(name, a.shape)
+    shutil.copyfile(f"{REF}/images/login.png", f"{OUT}/login.png")
+    bmp = load_bgr(f"{REF}/output.bmp")
+    np.savez_compressed(f"{OUT}/output_bmp_pin.npz", shape=np.array(bmp.shape), sha256=np.frombuffer(
+        hashlib.sha256(np.ascontiguousarray(bmp).tobytes()).digest(), np.uint8), crop=bmp[300:396, 500:628].copy())
+    print("output.bmp", bmp.shape, hashlib.sha256(np.ascontiguousarray(bmp).tobytes()).hexdigest())
 
 
 if __name__ == "__main__":

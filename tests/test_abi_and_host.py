@@ -180,6 +180,48 @@ def test_batching_decode_and_grouping(cd_bgr, login_bgr):
         ipa.group_by_shape([cd_bgr[:, :, 0]])
 
 
+def test_decode_matches_cv2_imread_artefact(login_bgr):
+    # origin cv2-artefact: output.bmp of the reference is imwrite(imread("images/login.png"))
+    # (NewVersion2/img2UML.py:16-17); the host loader must produce the very pixels cv2 decoded
+    import hashlib
+
+    import imageprocessing_amd as ipa
+    from tests.conftest import GOLDEN
+
+    pin = np.load(os.path.join(GOLDEN, "output_bmp_pin.npz"))
+    blob = open(os.path.join(GOLDEN, "login.png"), "rb").read()
+    got = ipa.decode_bgr(blob)
+    assert got.dtype == np.uint8 and tuple(got.shape) == tuple(pin["shape"]) == (840, 1140, 3)
+    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest() == pin["sha256"].tobytes()
+    assert np.array_equal(got[300:396, 500:628], pin["crop"])
+    assert np.array_equal(got, login_bgr)  # and the decoded fixture the GPU tests use is the same array
+
+
+def test_decode_applies_exif_orientation_and_handles_16_bit():
+    # cv2.imdecode(IMREAD_COLOR) turns the image as its EXIF orientation says and scales 16-bit files to 8 bits
+    import io
+
+    from PIL import Image
+
+    import imageprocessing_amd as ipa
+
+    rgb = np.random.default_rng(4).integers(0, 256, (20, 33, 3), dtype=np.uint8)
+    im = Image.fromarray(rgb)
+    ex = Image.Exif()
+    ex[0x0112] = 6  # rotate 90 degrees clockwise for display
+    buf = io.BytesIO()
+    im.save(buf, format="PNG", exif=ex)
+    got = ipa.decode_bgr(buf.getvalue())
+    assert got.shape == (33, 20, 3)
+    assert np.array_equal(got, np.rot90(rgb, -1)[:, :, ::-1])
+    g16 = (np.arange(40 * 50, dtype=np.uint32).reshape(40, 50) * 31 % 65536).astype(np.uint16)
+    buf = io.BytesIO()
+    Image.fromarray(g16).save(buf, format="PNG")
+    got = ipa.decode_bgr(buf.getvalue())
+    assert got.shape == (40, 50, 3) and np.array_equal(got[:, :, 0], (g16 >> 8).astype(np.uint8))
+    assert np.array_equal(got[:, :, 0], got[:, :, 2])
+
+
 def test_c_example_builds_and_links():
     # the plain C program of tests/c_abi/ compiles against include/ipamd.h and links the library
     import subprocess
