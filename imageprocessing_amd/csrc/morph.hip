@@ -653,6 +653,262 @@ __global__ __launch_bounds__(256) void k_morph_col(Plane src, Plane dst, int w, 
     }
 }
 
+
+// ---- general 8-bit, O(1) per pixel in the kernel length ---------------------------------------
+//
+// Rows: a wave holds 1024 consecutive columns of TWO adjacent image rows in registers, 16 columns
+// per lane, one dword per column (low half = upper row, high half = lower row), so that one packed
+// 16-bit min handles both rows.  A k-long window minimum is built by doubling: M_2s[x] =
+// min(M_s[x], M_s[x +- s]) for s = 1, 2, 4, .. up to the largest power of two p <= k, then one more
+// min with a copy displaced by k - p.  Every displacement is a power of two (k - p is applied bit by
+// bit), so a displacement below 16 is a renaming of the lane's registers plus one lane-to-lane move
+// for the columns that cross, and a displacement of 16 q is a move from lane +- q.  The direction of
+// each round is chosen so that the backward reach adds up to the anchor: no final realignment.
+// A maximum is the minimum of the complemented bytes.  Both stages of an open / close run on the
+// registers; columns outside the image are set to the identity before each stage.
+typedef unsigned short mus2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_min16(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(mus2, a), __builtin_bit_cast(mus2, b)));
+}
+__device__ __forceinline__ u32 lane_up1(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }    // from lane + 1
+__device__ __forceinline__ u32 lane_down1(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }  // from lane - 1
+
+constexpr int RD_COLS = 16;            // columns per lane
+constexpr int RD_WAVE = 64 * RD_COLS;  // columns per wave
+
+// o[i] = m at column (own column i) + DIR * 2^J; columns beyond the wave's ends hold junk
+template <int J, int DIR>
+__device__ __forceinline__ void rd_shift(const u32 (&m)[RD_COLS], u32 (&o)[RD_COLS])
+{
+    if (J < 4) {
+        constexpr int r = 1 << (J < 4 ? J : 0);
+#pragma unroll
+        for (int i = 0; i < RD_COLS; i++) {
+            if (DIR > 0) o[i] = i + r < RD_COLS ? m[(i + r) % RD_COLS] : lane_up1(m[(i + r) % RD_COLS]);
+            else o[i] = i - r >= 0 ? m[(i - r + RD_COLS) % RD_COLS] : lane_down1(m[(i - r + RD_COLS) % RD_COLS]);
+        }
+    } else {
+        constexpr int q = 1 << (J >= 4 ? J - 4 : 0);
+#pragma unroll
+        for (int i = 0; i < RD_COLS; i++) {
+            if (q == 1) o[i] = DIR > 0 ? lane_up1(m[i]) : lane_down1(m[i]);
+            else o[i] = DIR > 0 ? (u32)__shfl_down((int)m[i], q) : (u32)__shfl_up((int)m[i], q);
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void rd_shift_dir(const u32 (&m)[RD_COLS], u32 (&o)[RD_COLS], bool backward)
+{
+    if (backward) rd_shift<J, -1>(m, o);
+    else rd_shift<J, 1>(m, o);
+}
+
+// in place: m[x] = min over columns [x - a, x - a + k - 1] (16-bit halves independently); k, a wave-uniform
+__device__ __forceinline__ void rd_window_min(u32 (&m)[RD_COLS], int k, int a)
+{
+    int p = 1;
+    while (p * 2 <= k) p *= 2;
+    const int t = k - p;
+    const bool final_back = a > p - 1;
+    const int abits = final_back ? a - t : a;
+    u32 o[RD_COLS];
+#define RD_ROUND(J)                                               \
+    if ((1 << J) < p) {                                           \
+        rd_shift_dir<J>(m, o, ((abits >> J) & 1) != 0);           \
+        _Pragma("unroll") for (int i = 0; i < RD_COLS; i++) m[i] = pk_min16(m[i], o[i]); \
+    }
+    RD_ROUND(0) RD_ROUND(1) RD_ROUND(2) RD_ROUND(3) RD_ROUND(4) RD_ROUND(5) RD_ROUND(6) RD_ROUND(7) RD_ROUND(8)
+#undef RD_ROUND
+    if (t > 0) {
+        u32 c[RD_COLS];
+#pragma unroll
+        for (int i = 0; i < RD_COLS; i++) c[i] = m[i];
+#define RD_MOVE(J)                                                \
+    if ((t >> J) & 1) {                                           \
+        rd_shift_dir<J>(c, o, final_back);                        \
+        _Pragma("unroll") for (int i = 0; i < RD_COLS; i++) c[i] = o[i]; \
+    }
+        RD_MOVE(0) RD_MOVE(1) RD_MOVE(2) RD_MOVE(3) RD_MOVE(4) RD_MOVE(5) RD_MOVE(6) RD_MOVE(7) RD_MOVE(8)
+#undef RD_MOVE
+#pragma unroll
+        for (int i = 0; i < RD_COLS; i++) m[i] = pk_min16(m[i], c[i]);
+    }
+}
+
+// One wave = one pair of rows x one strip of `useful` output columns (+ halo).  nops = 1 (erode or
+// dilate) or 2 (open / close, second stage of the other kind).  halo_l is a multiple of 16.
+__global__ __launch_bounds__(256) void k_morph_row_dbl(Plane src, Plane dst, int w, int h, int strips, int pairs, int useful,
+                                                       int halo_l, int nops, int first_dil, int k, int a, long long nwaves)
+{
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_id >= nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const u32 wid = (u32)wave_id;
+    const u32 t1 = wid / (u32)strips;
+    const int sx = (int)(wid - t1 * (u32)strips);
+    const int b = (int)(t1 / (u32)pairs), rp = (int)(t1 - (u32)b * (u32)pairs);
+    const int y = 2 * rp;
+    const int x0 = sx * useful - halo_l + RD_COLS * lane;  // first column of this lane (a multiple of 16)
+    const bool in_row = x0 >= 0 && x0 < w;
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    if (in_row) {
+        ra = *(const uint4*)(src.row(b, y) + x0);
+        if (y + 1 < h) rb = *(const uint4*)(src.row(b, y + 1) + x0);
+    }
+    u32 m[RD_COLS];
+    {
+        const u32 A[4] = {ra.x, ra.y, ra.z, ra.w}, B[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            m[4 * j + 0] = __builtin_amdgcn_perm(B[j], A[j], 0x0c040c00u);
+            m[4 * j + 1] = __builtin_amdgcn_perm(B[j], A[j], 0x0c050c01u);
+            m[4 * j + 2] = __builtin_amdgcn_perm(B[j], A[j], 0x0c060c02u);
+            m[4 * j + 3] = __builtin_amdgcn_perm(B[j], A[j], 0x0c070c03u);
+        }
+    }
+    // columns of this lane inside the image (bit i = column x0 + i)
+    u32 inside = 0;
+    if (x0 + RD_COLS > 0 && x0 < w) {
+        const int lo = x0 < 0 ? -x0 : 0, hi = w - x0 < RD_COLS ? w - x0 : RD_COLS;
+        inside = ((hi >= 32 ? 0u : (1u << hi)) - 1u) & ~((1u << lo) - 1u);
+    }
+    const bool border_wave = sx * useful - halo_l < 0 || sx * useful - halo_l + RD_WAVE > w;  // wave-uniform
+    for (int op = 0; op < nops; op++) {
+        const bool dil = (first_dil != 0) != (op == 1);
+        if (dil) {
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) m[i] ^= 0x00ff00ffu;
+        }
+        if (border_wave) {
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) m[i] = (inside >> i) & 1u ? m[i] : 0x00ff00ffu;
+        }
+        rd_window_min(m, k, a);
+        if (dil) {
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) m[i] ^= 0x00ff00ffu;
+        }
+    }
+    const int ux = sx * useful;
+    if (in_row && x0 >= ux && x0 < ux + useful) {
+        u32 oa[4], ob[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            oa[j] = __builtin_amdgcn_perm(m[4 * j + 1], m[4 * j], 0x0c0c0400u) | __builtin_amdgcn_perm(m[4 * j + 3], m[4 * j + 2], 0x04000c0cu);
+            ob[j] = __builtin_amdgcn_perm(m[4 * j + 1], m[4 * j], 0x0c0c0602u) | __builtin_amdgcn_perm(m[4 * j + 3], m[4 * j + 2], 0x06020c0cu);
+        }
+        *(uint4*)(dst.row(b, y) + x0) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+        if (y + 1 < h) *(uint4*)(dst.row(b, y + 1) + x0) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+    }
+}
+
+// Columns: van Herk / Gil-Werman.  The rows are cut into blocks of k; within a block P[i] is the
+// minimum from the block's first row to row i and S[i] the minimum from row i to its last row.  A
+// window of k rows that starts at row lo of block j is S_j[lo] and P_{j+1}[lo + k - 1]: three
+// min operations per pixel whatever k is.  One wave walks down a strip 256 columns wide, lane = 4
+// adjacent columns (one dword); a block's rows are kept in LDS (k dwords per lane) while the prefix
+// runs in a register, at the end of the block the stored rows are turned into S in place.  Rows
+// outside the image count as the identity.  Bands of rows give the parallelism; a band starts at the
+// block boundary at or above its first window.
+// acc = per-byte min (max) of acc and v: four byte-selecting 16-bit instructions, each replacing one byte of acc
+// (a partial write of a register needs one wait state before the register is read again)
+template <bool DIL>
+__device__ __forceinline__ void bytes_minmax_acc(u32& acc, u32 v)
+{
+    if (DIL)
+        asm("v_max_u16_sdwa %0, %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\ts_nop 0\n\t"
+            "v_max_u16_sdwa %0, %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\ts_nop 0\n\t"
+            "v_max_u16_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\ts_nop 0\n\t"
+            "v_max_u16_sdwa %0, %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\ts_nop 0"
+            : "+v"(acc) : "v"(v));
+    else
+        asm("v_min_u16_sdwa %0, %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\ts_nop 0\n\t"
+            "v_min_u16_sdwa %0, %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\ts_nop 0\n\t"
+            "v_min_u16_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2\n\ts_nop 0\n\t"
+            "v_min_u16_sdwa %0, %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\ts_nop 0"
+            : "+v"(acc) : "v"(v));
+}
+
+template <bool DIL>
+__global__ __launch_bounds__(64) void k_morph_col_vhgw(Plane src, Plane dst, int w, int h, int dwords, int strips, int bands,
+                                                       int band_rows, int k, int a)
+{
+    extern __shared__ u32 ring[];  // [k][64]
+    const int lane = threadIdx.x;
+    int blk = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);  // neighbouring strips (they share cache lines) on one XCD
+    const int sx = blk % strips;
+    blk /= strips;
+    const int band = blk % bands, b = blk / bands;
+    const int dx = sx * 64 + lane;
+    const bool live = dx < dwords;
+    const int Y0 = band * band_rows, Y1 = min(Y0 + band_rows, h);
+    const u32 ident = DIL ? 0u : 0xffffffffu;
+    // first block: the one that holds row Y0 - a (floor division for negative rows)
+    const int lo0 = Y0 - a;
+    int r = (lo0 >= 0 ? lo0 / k : -((-lo0 + k - 1) / k)) * k;
+    const u8* const sbase = src.p + (size_t)b * src.stride + (size_t)dx * 4;
+    u8* const dbase = dst.p + (size_t)b * dst.stride + (size_t)dx * 4;
+    auto load_row = [&](int yy) -> u32 {
+        u32 v = ident;
+        if (live && yy >= 0 && yy < h) v = *(const u32*)(sbase + (size_t)yy * src.pitch);
+        return v;
+    };
+    constexpr int PF = 8;  // rows in flight ahead of the row being consumed
+    u32 q[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) q[j] = load_row(r + j);
+    int ahead = r + PF;  // next row to request
+    bool have_prev = false;
+    for (; r - (k - 1) + a < Y1; r += k) {  // the block's first output row is r - (k-1) + a
+        u32 pre = ident;
+        for (int i0 = 0; i0 < k; i0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const int i = i0 + j;
+                if (i < k) {  // (wave-uniform)
+                    const u32 v = q[j];
+                    q[j] = load_row(ahead++);
+                    const int yy = r + i;
+                    bytes_minmax_acc<DIL>(pre, v);
+                    // the window that ends at row yy: output row yo; its first row is row i + 1 of the previous block
+                    const int yo = yy - (k - 1) + a;
+                    u32 out = pre;
+                    if (i < k - 1) {
+                        const u32 sprev = have_prev ? ring[(i + 1) * 64 + lane] : ident;
+                        bytes_minmax_acc<DIL>(out, sprev);
+                    }
+                    ring[i * 64 + lane] = v;
+                    if (live && yo >= Y0 && yo < Y1 && (have_prev || i == k - 1)) *(u32*)(dbase + (size_t)yo * dst.pitch) = out;
+                }
+            }
+            // a block that ends inside a group of PF: the rows already requested belong to the next block
+            if (i0 + PF > k) {
+                const int used = k - i0;  // 1 .. PF-1 rows of this group were consumed: move the rest to the front
+                u32 t[PF];
+#pragma unroll
+                for (int j = 0; j < PF; j++) t[j] = q[j];
+#pragma unroll
+                for (int j = 0; j < PF; j++) {
+                    u32 v = t[j];
+#pragma unroll
+                    for (int u = 1; u < PF; u++)
+                        if (used == u) v = t[(j + u) % PF];
+                    q[j] = v;
+                }
+            }
+        }
+        // suffix minima of the block, in place
+        u32 suf = ring[(k - 1) * 64 + lane];
+        for (int i = k - 2; i >= 0; i--) {
+            bytes_minmax_acc<DIL>(suf, ring[i * 64 + lane]);
+            ring[i * 64 + lane] = suf;
+        }
+        have_prev = true;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy_plane(Plane src, Plane dst, int cpr, int h, long long total)
 {
     const long long step = (long long)gridDim.x * blockDim.x;
@@ -796,6 +1052,25 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
     return IPA_OK;
 }
 
+// Row pass in registers (k_morph_row_dbl): nops stages with the same kernel length kx and anchor ax.
+// Returns 1 when the shape is outside what the kernel covers (the caller then uses k_morph_row).
+static int launch_morph_row_dbl(Plane src, Plane dst, int w, int h, int batch, int nops, int first_dil, int kx, int ax,
+                                hipStream_t st)
+{
+    const int halo_l = (int)align_up((size_t)(nops * ax), 16), halo_r = nops * (kx - 1 - ax);
+    const int useful = (RD_WAVE - halo_l - halo_r) & ~15;
+    if (useful < 256) return 1;  // long kernels: most of a wave would be halo
+    const int strips = cdiv(w, useful), pairs = cdiv(h, 2);
+    const long long nwaves = (long long)strips * pairs * batch;
+    if (nwaves >= 0x7fffffffLL) return 1;
+    hipLaunchKernelGGL(k_morph_row_dbl, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h, strips, pairs, useful,
+                       halo_l, nops, first_dil, kx, ax, nwaves);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+static bool g_vhgw_attr_set = false;
+
 // One general 8-bit erode/dilate pass pair (rows then columns) with folded sizes.
 int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batch, int is_dilate, int kx, int ky,
                          int ax, int ay, hipStream_t st)
@@ -803,25 +1078,57 @@ int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batc
     Plane cur = src;
     if (kx > 1) {
         Plane out = ky > 1 ? tmp : dst;
-        int segs = cdiv(w, 1024);
-        int L = (ax + 3) & ~3, R = (kx - 1 - ax + 3) & ~3;
-        size_t lds = (size_t)1024 + L + R;
-        if (lds > 64 * 1024) {
-            ipa_set_error("morphology: kernel width %d too large", kx);
-            return IPA_ERR_ARG;
+        int rc = launch_morph_row_dbl(cur, out, w, h, batch, 1, is_dilate, kx, ax, st);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            int segs = cdiv(w, 1024);
+            int L = (ax + 3) & ~3, R = (kx - 1 - ax + 3) & ~3;
+            size_t lds = (size_t)1024 + L + R;
+            if (lds > 64 * 1024) {
+                ipa_set_error("morphology: kernel width %d too large", kx);
+                return IPA_ERR_ARG;
+            }
+            long long blocks = (long long)segs * h * batch;
+            hipLaunchKernelGGL(k_morph_row, dim3((unsigned)blocks), dim3(256), lds, st, cur, out, w, h, segs, kx, ax,
+                               is_dilate);
+            IPA_LAUNCH_CHECK();
         }
-        long long blocks = (long long)segs * h * batch;
-        hipLaunchKernelGGL(k_morph_row, dim3((unsigned)blocks), dim3(256), lds, st, cur, out, w, h, segs, kx, ax,
-                           is_dilate);
-        IPA_LAUNCH_CHECK();
         cur = out;
     }
     if (ky > 1) {
-        int dwords = cdiv(w, 4), rowgroups = cdiv(h, 4);
-        long long total = (long long)dwords * rowgroups * batch;
-        hipLaunchKernelGGL(k_morph_col, dim3(stream_grid(total, 256)), dim3(256), 0, st, cur, dst, w, h, dwords,
-                           rowgroups, ky, ay, is_dilate, total);
-        IPA_LAUNCH_CHECK();
+        const int dwords = cdiv(w, 4);
+        const size_t lds = (size_t)ky * 64 * sizeof(u32);
+        if (ky >= 6 && lds <= 150 * 1024) {
+            // van Herk / Gil-Werman down the columns; bands of rows (at least four kernel lengths each, so that
+            // the rows a band reads above its first output stay a small part) give the launch its parallelism
+            const int strips = cdiv(dwords, 64);
+            int band_rows = h;
+            while (band_rows / 2 >= 4 * ky && (long long)strips * cdiv(h, band_rows) * batch < 4096) band_rows = (band_rows + 1) / 2;
+            const int bands = cdiv(h, band_rows);
+            const long long blocks = (long long)strips * bands * batch;
+            if (blocks > 0x7fffffffLL) {
+                ipa_set_error("morphology: too many strips");
+                return IPA_ERR_ARG;
+            }
+            if (lds > 48 * 1024 && !g_vhgw_attr_set) {
+                IPA_HIP(hipFuncSetAttribute((const void*)k_morph_col_vhgw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                IPA_HIP(hipFuncSetAttribute((const void*)k_morph_col_vhgw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                g_vhgw_attr_set = true;
+            }
+            if (is_dilate)
+                hipLaunchKernelGGL(k_morph_col_vhgw<true>, dim3((unsigned)blocks), dim3(64), lds, st, cur, dst, w, h, dwords, strips, bands,
+                                   band_rows, ky, ay);
+            else
+                hipLaunchKernelGGL(k_morph_col_vhgw<false>, dim3((unsigned)blocks), dim3(64), lds, st, cur, dst, w, h, dwords, strips, bands,
+                                   band_rows, ky, ay);
+            IPA_LAUNCH_CHECK();
+        } else {
+            int rowgroups = cdiv(h, 4);
+            long long total = (long long)dwords * rowgroups * batch;
+            hipLaunchKernelGGL(k_morph_col, dim3(stream_grid(total, 256)), dim3(256), 0, st, cur, dst, w, h, dwords,
+                               rowgroups, ky, ay, is_dilate, total);
+            IPA_LAUNCH_CHECK();
+        }
         cur = dst;
     }
     if (cur.p == src.p) {
@@ -914,6 +1221,10 @@ IPA_EXPORT int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_str
         return launch_bitmorph(bits, bpw, bsw, d, width, height, batch, first_dil, nops, KX, KY, AX, AY, 0, vmax, st);
     }
     if (nops == 1) return launch_morph_generic(s, d, t1, width, height, batch, first_dil, KX, KY, AX, AY, st);
+    if (KY == 1) {  // open / close along the rows only: both stages in one pass over the registers
+        const int rc1 = launch_morph_row_dbl(s, d, width, height, batch, 2, first_dil, KX, AX, st);
+        if (rc1 <= 0) return rc1;
+    }
     int rc = launch_morph_generic(s, t2, t1, width, height, batch, first_dil, KX, KY, AX, AY, st);
     if (rc) return rc;
     return launch_morph_generic(t2, d, t1, width, height, batch, !first_dil, KX, KY, AX, AY, st);

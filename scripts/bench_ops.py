@@ -95,6 +95,11 @@ def main():
         ("erode 3x3 it=2 (binary)", 2 * px, morph(0, 3, 3, 2, 1, thr)),
         ("dilate 3x3 it=1 (gray)", 2 * px, morph(1, 3, 3, 1, 0, gray)),
         ("open 15x1 it=2 (gray)", 2 * px, morph(2, 15, 1, 2, 0, gray)),
+        ("open 1x15 it=2 (gray)", 2 * px, morph(2, 1, 15, 2, 0, gray)),
+        ("erode 101x1 (gray)", 2 * px, morph(0, 101, 1, 1, 0, gray)),
+        ("erode 1x101 (gray)", 2 * px, morph(0, 1, 101, 1, 0, gray)),
+        ("open 101x101 (gray)", 2 * px, morph(2, 101, 101, 1, 0, gray)),
+        ("close 3x3 it=2 (gray)", 2 * px, morph(3, 3, 3, 2, 0, gray)),
         ("Canny 50/150", 2 * px, lambda: chk(L.ipa_canny_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 50.0, 150.0, ws.data_ptr(), ws.numel(), st))),
         ("HoughLines accumulator", px + acc_bytes, lambda: chk(L.ipa_hough_accum_u8(edges.ptr, edges.pitch, edges.stride, w, h, n, 1.0, np.pi / 180, acc.data_ptr(), acc.stride(0), seg.data_ptr(), w * h // 4, cnt.data_ptr(), ws.data_ptr(), ws.numel(), st))),
         ("HoughLinesP 100/100/10", px, lambda: chk(L.ipa_hough_lines_p_u8(edges.ptr, edges.pitch, edges.stride, w, h, n, 1.0, np.pi / 180, 100, 100, 10, w * h // 4, hp_lines.data_ptr(), 4096, nbox.data_ptr(), hp_ws.data_ptr(), hp_ws.numel(), st))),
