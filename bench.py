@@ -369,16 +369,22 @@ def main():
                     "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launch_ms": stages[dom]["ms"], "algorithmic_bytes_per_launch": alg[dom] * batch}
             if dom == "hough_vote" and fe.hough:
-                # the vote is bound by LDS atomics, not by HBM: also quote it against the LDS atomic rate
-                # measured on this chip for random addresses (scripts/micro/lds_big.hip: 1024 x 20000
-                # ds_add_u32 lanes per CU in 1.03 ms = 19.9e9 lane-atomics per second and CU)
+                # The vote is bound by LDS atomics, not by HBM: also quote it against the LDS atomic rates measured on
+                # this chip with 16 waves per CU (scripts/micro/lds_rate.hip, lds_rand.hip; clocks at 2.4 GHz):
+                # a ds_add_u32 wave instruction takes 4.37 clk when its 64 addresses fall into different banks
+                # (35.1e9 lane-atomics per second and CU) and 8.0-8.5 clk on addresses that are random and fresh for
+                # every instruction, which is what Hough bins of scattered edge pixels are (18.7e9).
                 props = torch.cuda.get_device_properties(dev)
                 votes = float(fe.point_counts[:batch].sum().item()) * fe.na
-                ceiling = 19.9e9 * props.multi_processor_count
                 rate = votes / (stages[dom]["ms"] * 1e-3)
-                roof["lds_atomics"] = {"votes_per_s": round(rate, 0), "ceiling_votes_per_s": round(ceiling, 0),
-                                       "frac": round(rate / ceiling, 4),
-                                       "note": "180 votes per edge pixel, one ds_add_u32 lane each; ceiling = measured random-address rate"}
+                free_rate = 35.1e9 * props.multi_processor_count
+                rand_rate = 18.7e9 * props.multi_processor_count
+                roof["lds_atomics"] = {"votes_per_s": round(rate, 0), "ceiling_votes_per_s": round(free_rate, 0),
+                                       "frac": round(rate / free_rate, 4),
+                                       "random_address_votes_per_s": round(rand_rate, 0),
+                                       "frac_of_random_address_rate": round(rate / rand_rate, 4),
+                                       "note": "180 votes per edge pixel, one ds_add_u32 lane each; ceiling = conflict-free rate; "
+                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.69 (profiles/pmc_r02b_4k_x1024_summary.txt)"}
         cpu = None
         if not args.no_cpu:
             try:
