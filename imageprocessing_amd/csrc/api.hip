@@ -309,7 +309,10 @@ struct Chunk {
     void *canny_ws, *hough_ws, *blur_ws;
     u8* blur_plane;
     size_t bpw, bsw;
+    bool precleared;  // the gray kernel zeroes the Canny tile flags and the Hough point counts (short passes)
 };
+
+bool fused_points();
 
 int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray, uint8_t* thresh,
                uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch, size_t plane_stride, int32_t* accum,
@@ -347,6 +350,9 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
     double lo = canny_lo, hi = canny_hi;
     if (lo > hi) { double t = lo; lo = hi; hi = t; }
     C.lo = (int)floor(lo), C.hi = (int)floor(hi);
+    // short passes (a few images): the few kilobytes of flags and counters are zeroed inside the gray kernel
+    static const int preclear = getenv("IPA_PRECLEAR") ? atoi(getenv("IPA_PRECLEAR")) : 1;  // 0: separate memsets (A/B)
+    C.precleared = preclear && edges != nullptr && !fused_points() && canny_ws_bytes(width, height, batch) <= 64 * 1024 && batch <= 1024;
     return IPA_OK;
 }
 
@@ -354,7 +360,15 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
 int stage_gray(const Chunk& C, hipStream_t st)
 {
     ProfScope ps(PROF_GRAY_THRESH, st);
-    return launch_bgr2gray(C.B, C.G, C.T, C.bits, C.bpw, C.bsw, C.width, C.height, C.batch, C.tv, 255, 1, st);
+    ClearList clr = {{nullptr, nullptr}, {0, 0}};
+    if (C.precleared) {
+        canny_flag_area(C.width, C.height, C.batch, C.canny_ws, &clr.p[0], &clr.n[0]);
+        if (C.accum) {
+            clr.p[1] = (u32*)C.point_counts;
+            clr.n[1] = (u32)C.batch;
+        }
+    }
+    return launch_bgr2gray(C.B, C.G, C.T, C.bits, C.bpw, C.bsw, C.width, C.height, C.batch, C.tv, 255, 1, st, clr);
 }
 
 int stage_opens(const Chunk& C, hipStream_t st)
@@ -400,10 +414,10 @@ int stage_edges(const Chunk& C, bool with_lists, hipStream_t st)
         sink = hough_point_sink(C.width, C.height, C.max_points, C.point_counts, C.hough_ws);
         IPA_HIP(hipMemsetAsync(C.point_counts, 0, sizeof(int32_t) * (size_t)C.batch, st));
     }
-    rc = run_canny(csrc, C.E, C.width, C.height, C.batch, C.lo, C.hi, C.canny_ws, C.L.canny_bytes, sink, st);
+    rc = run_canny(csrc, C.E, C.width, C.height, C.batch, C.lo, C.hi, C.canny_ws, C.L.canny_bytes, sink, st, C.precleared);
     if (rc || !C.accum || !with_lists || fused_points()) return rc;
     return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
-                           C.point_counts, C.hough_ws, C.L.hough_bytes, HOUGH_COMPACT_ONLY, 0, st);
+                           C.point_counts, C.hough_ws, C.L.hough_bytes, HOUGH_COMPACT_ONLY, 0, st, C.precleared);
 }
 
 // lists_ready: stage_edges has already made the edge-pixel lists
@@ -412,7 +426,7 @@ int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t s
     if (!C.accum) return IPA_OK;
     return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
                            C.point_counts, C.hough_ws, C.L.hough_bytes,
-                           (lists_ready || fused_points()) ? HOUGH_VOTE_ONLY : HOUGH_ALL, resident_wgs, st);
+                           (lists_ready || fused_points()) ? HOUGH_VOTE_ONLY : HOUGH_ALL, resident_wgs, st, C.precleared);
 }
 
 // Events that order the helper streams.  They come from a per-thread pool that lives as long as the

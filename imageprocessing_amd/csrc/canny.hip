@@ -743,8 +743,16 @@ size_t canny_ws_bytes(int w, int h, int batch)
 // resolved by one workgroup each with no host interaction; larger images are cut
 // into regions and the stream is synchronised to learn whether a further
 // hysteresis launch is needed.
+// The part of the workspace run_canny wants zeroed before its first kernel (tile flags and the first set of marks).
+void canny_flag_area(int w, int h, int batch, void* ws, u32** p, u32* dwords)
+{
+    const size_t ntiles = (size_t)cdiv(w, TW) * cdiv(h, TH) * batch;
+    *p = (u32*)ws;
+    *dwords = (u32)(2 * align_up(ntiles, 256) / 4);
+}
+
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
-              PointSink sink, hipStream_t st)
+              PointSink sink, hipStream_t st, bool flags_cleared)
 {
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     const long long ntiles_ll = (long long)tiles_x * tiles_y * batch;
@@ -785,7 +793,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         if (mode == 1 && (stream_ok || sink.pts)) {
             IPA_REQUIRE(stream_ok, IPA_ERR_ARG, "Canny: image too small or too large for the fused edge-list path");
             // (whole multiples of 256 bytes: the runtime then clears them with one kernel instead of two)
-            IPA_HIP(hipMemsetAsync(W.has_weak, 0, (two_step ? 2 : 1) * align_up(ntiles, 256), st));
+            if (!flags_cleared) IPA_HIP(hipMemsetAsync(W.has_weak, 0, (two_step ? 2 : 1) * align_up(ntiles, 256), st));
             const int strips_x = cdiv(w, ST_COLS);
             // short bands while 64-row bands would give fewer than 4096 waves (16 per CU)
             const bool short_bands = (long long)strips_x * cdiv(h, ST_ROWS) * batch < 4096;
@@ -811,7 +819,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     }
     ProfScope ps(PROF_HYSTERESIS, st);
     if (two_step) {
-        if (mode != 1) IPA_HIP(hipMemsetAsync(pending, 0, ntiles, st));  // (the tile kernel writes has_weak itself)
+        if (mode != 1 && !flags_cleared) IPA_HIP(hipMemsetAsync(pending, 0, ntiles, st));  // (the tile kernel writes has_weak itself)
         const int rx = cdiv(tiles_x, small_side), ry = cdiv(tiles_y, small_side);
         CannyWs W1 = W;
         W1.pending = pending;

@@ -32,8 +32,15 @@ __device__ __forceinline__ u32 luma_dot(u32 px)
 template <bool THRESH, bool PACK>
 __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* __restrict__ bits,
                                                   size_t bpw, size_t bsw, int w, int h, int cpr, int ithresh,
-                                                  u32 v_above, u32 v_below)
+                                                  u32 v_above, u32 v_below, ClearList clr)
 {
+    if (clr.n[0] | clr.n[1]) {  // (wave-uniform) the first workgroup zeroes the scratch of the stages that follow
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+            const u32 t = threadIdx.y * 64 + threadIdx.x;
+            for (int a = 0; a < 2; a++)
+                for (u32 i = t; i < clr.n[a]; i += 256) clr.p[a][i] = 0;
+        }
+    }
     const int cx = blockIdx.x * 64 + threadIdx.x;
     const int b = blockIdx.z;
     // a wave's lanes share threadIdx.y: row numbers and row addresses are wave-uniform (scalar)
@@ -319,7 +326,7 @@ int sat_u8_round(double v)
 }  // namespace
 
 int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch,
-                    int ithresh, int maxval, int inv, hipStream_t st)
+                    int ithresh, int maxval, int inv, hipStream_t st, ClearList clr)
 {
     int cpr = cdiv(w, 16);
     cpr += cpr & 1;
@@ -335,12 +342,13 @@ int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, siz
         const dim3 grid = rows_grid(cpr, h, nb), block = rows_block();
         // the bit plane holds "pixel is non-zero in the thresholded plane"
         if (bin.p && bits)
-            hipLaunchKernelGGL((k_bgr2gray<true, true>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb);
+            hipLaunchKernelGGL((k_bgr2gray<true, true>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
         else if (bin.p)
-            hipLaunchKernelGGL((k_bgr2gray<true, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb);
+            hipLaunchKernelGGL((k_bgr2gray<true, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
         else
-            hipLaunchKernelGGL((k_bgr2gray<false, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb);
+            hipLaunchKernelGGL((k_bgr2gray<false, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
         IPA_LAUNCH_CHECK();
+        clr.n[0] = clr.n[1] = 0;  // (only the first launch clears)
     }
     return IPA_OK;
 }

@@ -148,8 +148,15 @@ struct ProfScope {
 
 // ---- internal entry points shared between translation units --------------
 // (all enqueue on `st`; no validation: callers have validated)
+// Small scratch areas (sizes in dwords, 16-byte aligned starts) that the gray kernel zeroes on the side for the
+// stages behind it, so that a short pass does not spend launches on clearing a few kilobytes.
+struct ClearList {
+    u32* p[2];
+    u32 n[2];
+};
 int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bits_pitch_words, size_t bits_stride_words,
-                    int w, int h, int batch, int ithresh, int maxval, int inv, hipStream_t st);
+                    int w, int h, int batch, int ithresh, int maxval, int inv, hipStream_t st,
+                    ClearList clr = ClearList{{nullptr, nullptr}, {0, 0}});
 
 // bit-plane geometry: words per row rounded to a multiple of 32 (one 128-byte cache line), so
 // that the 128-byte pieces the producing waves write never share a line between workgroups
@@ -197,8 +204,10 @@ struct PointSink {
 };
 
 size_t canny_ws_bytes(int w, int h, int batch);
+// flags_cleared: the area canny_flag_area() names has been zeroed by the caller (on the same stream)
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
-              PointSink sink, hipStream_t st);
+              PointSink sink, hipStream_t st, bool flags_cleared = false);
+void canny_flag_area(int w, int h, int batch, void* ws, u32** p, u32* dwords);
 
 size_t hough_ws_bytes(int w, int h, int batch, int max_points);
 PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, void* ws);
@@ -207,6 +216,7 @@ int hough_segments(int numrho);
 // many workgroups (one per CU, each looping over its share of the work) so that it keeps half of every
 // CU while a streaming kernel of another stream uses the rest.
 enum HoughPhase { HOUGH_ALL = 0, HOUGH_VOTE_ONLY = 1, HOUGH_COMPACT_ONLY = 2 };
+// counts_cleared: point_counts has been zeroed by the caller (on the same stream)
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
                     int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
-                    int resident_wgs, hipStream_t st);
+                    int resident_wgs, hipStream_t st, bool counts_cleared = false);

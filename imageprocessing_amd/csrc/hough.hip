@@ -728,7 +728,7 @@ int hough_segments(int numrho) { return cdiv(numrho + 2, HOUGH_SEG); }
 
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
                     int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
-                    int resident_wgs, hipStream_t st)
+                    int resident_wgs, hipStream_t st, bool counts_cleared)
 {
     IPA_REQUIRE(w <= 65535 && h <= 65535, IPA_ERR_ARG, "HoughLines: image larger than 65535 pixels on a side");
     int numangle, numrho;
@@ -754,9 +754,13 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             T.c[n] = (float)(cos((double)ang) * irho);
         }
     }
-    const bool revote = getenv("IPA_VOTE_ONLY") != nullptr;  // experiments: re-vote the lists of the previous call
+#ifdef IPA_EXPERIMENTS
+    const bool revote = getenv("IPA_VOTE_ONLY") != nullptr;  // probes only: re-vote the lists of the previous call
+#else
+    const bool revote = false;
+#endif
     if (phase != HOUGH_VOTE_ONLY && !revote) {
-        IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+        if (!counts_cleared) IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
         ProfScope ps(PROF_HOUGH_COMPACT, st);
         const int cpr = cdiv(w, 16);
         static int cmode = -1;  // IPA_COMPACT_MODE=0 selects the grid-stride kernel
@@ -909,7 +913,8 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     const bool segmax_after = seg_max && A.slices > 1;  // computed from the finished accumulator
     if (seg_max && !A.segmax && !segmax_after)  // this kernel variant does not produce the maxima: mark every segment as worth reading
         IPA_HIP(hipMemsetD32Async((hipDeviceptr_t)seg_max, 0x7fffffff, (size_t)batch * numangle * A.nsegs, st));
-    size_t lds = (size_t)tg * span_words * 4 + lds_pad_kib("IPA_PAD_VOTE");
+    static const size_t vote_pad = lds_pad_kib("IPA_PAD_VOTE");
+    size_t lds = (size_t)tg * span_words * 4 + vote_pad;
     // a resident grid must not get two workgroups onto one CU: more than half of the CU's LDS each
     if (resident_wgs > 0 && lds < 81 * 1024) lds = 81 * 1024;
     if (lds > 48 * 1024 && !g_vote_attr_set) {
@@ -937,8 +942,12 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
         Ab.items = (u32)A.groups * (u32)A.slices * (u32)nb;
-        Ab.dbg_only_grp = getenv("IPA_VOTE_ONLY_GRP") ? atoi(getenv("IPA_VOTE_ONLY_GRP")) : -1;
-        Ab.dbg_trip_mask = getenv("IPA_VOTE_WRAP") ? (u32)atoi(getenv("IPA_VOTE_WRAP")) : 0xffffffffu;
+        Ab.dbg_only_grp = -1;
+        Ab.dbg_trip_mask = 0xffffffffu;
+#ifdef IPA_EXPERIMENTS  // probes only (scripts/): part of the angles / of the list
+        if (getenv("IPA_VOTE_ONLY_GRP")) Ab.dbg_only_grp = atoi(getenv("IPA_VOTE_ONLY_GRP"));
+        if (getenv("IPA_VOTE_WRAP")) Ab.dbg_trip_mask = (u32)atoi(getenv("IPA_VOTE_WRAP"));
+#endif
         static int resident_env = -1;  // IPA_VOTE_RESIDENT: force a resident grid of that many workgroups (multiple of 8)
         if (resident_env < 0) {
             const char* e = getenv("IPA_VOTE_RESIDENT");

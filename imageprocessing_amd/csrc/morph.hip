@@ -959,6 +959,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
         const char* e = getenv("IPA_BITMORPH_FAST");
         fast = e ? atoi(e) : 1;
     }
+    static const size_t morph_pad = lds_pad_kib("IPA_PAD_MORPH");
     if (fast && ky == 1 && kx > 1 && nops * ax <= 32 && nops * (kx - 1 - ax) <= 32) {
         const int words = cdiv(w, 32);
         for (int b0 = 0; b0 < batch; b0 += 65535) {
@@ -966,7 +967,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
             Plane db = dst;
             db.p += (size_t)b0 * dst.stride;
 #define IPA_H3(N, K, A)                                                                                          \
-    hipLaunchKernelGGL((k_bitmorph_h3<N, K, A>), rows_grid(words, h, nb), rows_block(), lds_pad_kib("IPA_PAD_MORPH"), st, bits + (size_t)b0 * bsw, \
+    hipLaunchKernelGGL((k_bitmorph_h3<N, K, A>), rows_grid(words, h, nb), rows_block(), morph_pad, st, bits + (size_t)b0 * bsw, \
                        bpw, bsw, db, w, h, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value,                   \
                        value_dev ? value_dev + b0 : nullptr)
             // the shapes of the parsers (15-pixel lines, 1 or 2 iterations) and of 3x3 open / close
@@ -993,7 +994,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
             db.p += (size_t)b0 * dst.stride;
             const dim3 grid((unsigned)cdiv(words, 64), (unsigned)cdiv(strips, 4), (unsigned)nb), block(64, 4);
             if (ky < 32)
-                hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, lds_pad_kib("IPA_PAD_MORPH"), st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
+                hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, morph_pad, st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
                                    strips, strip_rows, first_is_dilate, nops, ky, ay, (u32)value,
                                    value_dev ? value_dev + b0 : nullptr);
             else
