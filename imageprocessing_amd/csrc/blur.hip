@@ -9,6 +9,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -195,6 +196,163 @@ __global__ __launch_bounds__(256) void k_gauss5_stream(Plane src, Plane dst, int
         }
         if (writer && y < y1) *(u32*)(dimg + (size_t)((u32)y * dpitch + (u32)x)) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
         ra = rb; rb = rc; rc = rd; rd = re;
+    }
+}
+
+
+// ---- tiled Gaussian for 7 to 31 taps -------------------------------------------------------------
+// One workgroup = 256 x 32 output pixels.  The source tile with its halo (border rule applied while
+// loading) sits in LDS as bytes; the horizontal pass takes four taps per v_dot4_u32_u8 and leaves the
+// Q8.8 sums of all tile rows + vertical halo in LDS with two consecutive rows of a column in one dword;
+// the vertical pass takes two rows per v_dot2_u32_u16 (one packing of the taps for even, one for odd
+// output rows) and finishes the pixels.  Integer sums, so the result is that of the two fixed-point
+// passes k_gauss_row / k_gauss_col whatever the grouping; no intermediate plane in HBM, no per-tap
+// border logic.  Taps must fit a byte (the host checks; a lone tap of 256 takes the other kernels).
+constexpr int GT_W = 256, GT_H = 32, GT_MAX = 31;
+constexpr int GT_G4 = (GT_MAX + 3) / 4;      // groups of four horizontal taps
+constexpr int GT_G2 = (GT_MAX + 1) / 2 + 1;  // pairs of vertical taps (odd rows start half a pair early)
+typedef unsigned short gt_us2 __attribute__((ext_vector_type(2)));
+
+struct GaussTileTaps {
+    int nx, ny, border;
+    u32 x4[GT_G4];       // taps 4j .. 4j+3 as bytes
+    u32 y2e[GT_G2];      // taps (2j, 2j+1) as 16-bit halves
+    u32 y2o[GT_G2];      // taps (2j-1, 2j)
+};
+
+__global__ __launch_bounds__(256) void k_gauss_tile(Plane src, Plane dst, int w, int h, int tiles_x, int tiles_y, GaussTileTaps T)
+{
+    extern __shared__ __align__(16) u8 gt_smem[];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int tx = blk % tiles_x;
+    blk /= tiles_x;
+    const int ty = blk % tiles_y, b = blk / tiles_y;
+    const int rx = T.nx >> 1, ry = T.ny >> 1;
+    const int SR = GT_H + 2 * ry;                 // source rows in LDS (even)
+    const int SPW = (GT_W + 2 * rx + 3) / 4 + 2;  // source row pitch in dwords
+    u32* const s32 = (u32*)gt_smem;
+    u32* const hz = s32 + (size_t)SR * SPW;       // [SR / 2][GT_W]: rows 2q (low half) and 2q+1 (high half)
+    const int x0 = tx * GT_W, y0 = ty * GT_H;
+    const int border = T.border;
+    const int ng4 = (T.nx + 3) >> 2;
+    // ---- source tile: LDS column c <-> image column x0 - rx + c, LDS row r <-> image row y0 - ry + r.
+    // Wave v takes rows v, v + 4, ..; all of a thread's loads are issued before the first is used.
+    const bool interior = x0 - rx >= 0 && x0 - rx + 4 * SPW <= w && y0 - ry >= 0 && y0 + GT_H + ry <= h;  // (uniform)
+    if (interior) {
+        // no border in sight: one running pointer per lane
+        constexpr int RMAX = (GT_H + GT_MAX - 1 + 3) / 4;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+        const u8* p = src.row(b, y0 - ry + wv) + (x0 - rx) + 4 * ln;
+        const size_t step = 4 * src.pitch;
+        const bool second = ln + 64 < SPW;
+        u32 v[RMAX][2];
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {
+            if (wv + 4 * k < SR) {
+                v[k][0] = *(const u32*)p;
+                if (second) v[k][1] = *(const u32*)(p + 256);
+                p += step;
+            }
+        }
+        u32* o = s32 + wv * SPW + ln;
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {
+            if (wv + 4 * k < SR) {
+                o[0] = v[k][0];
+                if (second) o[64] = v[k][1];
+                o += 4 * SPW;
+            }
+        }
+    } else {
+        constexpr int RMAX = (GT_H + GT_MAX - 1 + 3) / 4;  // rows per wave for the largest kernel
+        const int wv = tid >> 6, ln = tid & 63;
+        u32 v[RMAX][2];
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {
+            const int r = wv + 4 * k;
+            v[k][0] = v[k][1] = 0;
+            if (r < SR) {  // (wave-uniform)
+                const int yy = border_idx(y0 - ry + r, h, border);
+                if (yy >= 0) {
+                    const u8* row = src.row(b, yy);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        const int c4 = ln + 64 * m, gx = x0 - rx + 4 * c4;
+                        if (c4 < SPW && gx >= 0 && gx + 4 <= w) v[k][m] = *(const u32*)(row + gx);  // (any byte alignment)
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {
+            const int r = wv + 4 * k;
+            if (r < SR) {
+                const int yy = border_idx(y0 - ry + r, h, border);
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const int c4 = ln + 64 * m, gx = x0 - rx + 4 * c4;
+                    if (c4 >= SPW) continue;
+                    u32 val = v[k][m];
+                    if (yy >= 0 && !(gx >= 0 && gx + 4 <= w)) {  // columns across the image border: byte by byte
+                        const u8* row = src.row(b, yy);
+                        for (int j = 0; j < 4; j++) {
+                            const int xx = border_idx(gx + j, w, border);
+                            if (xx >= 0) val |= (u32)row[xx] << (8 * j);
+                        }
+                    }
+                    s32[r * SPW + c4] = val;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass: item = (pair of rows, 4 adjacent columns)
+    for (int e = tid; e < (SR / 2) * (GT_W / 4); e += 256) {
+        const int q = e >> 6, c4 = e & 63;
+        u32 acc[2][4];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32* rowp = s32 + (2 * q + half) * SPW + c4;  // byte 0 = first tap of output column x0 + 4 c4
+            u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            u32 cur = rowp[0];
+#pragma unroll
+            for (int j = 0; j < GT_G4; j++) {
+                if (j >= ng4) break;  // (wave-uniform)
+                const u32 nxt = rowp[j + 1];
+                const u32 k = T.x4[j];
+                a0 = __builtin_amdgcn_udot4(cur, k, a0, false);
+                a1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(nxt, cur, 1), k, a1, false);
+                a2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(nxt, cur, 2), k, a2, false);
+                a3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(nxt, cur, 3), k, a3, false);
+                cur = nxt;
+            }
+            acc[half][0] = a0; acc[half][1] = a1; acc[half][2] = a2; acc[half][3] = a3;
+        }
+        *(uint4*)(hz + (size_t)q * GT_W + 4 * c4) = make_uint4(acc[0][0] | (acc[1][0] << 16), acc[0][1] | (acc[1][1] << 16),
+                                                              acc[0][2] | (acc[1][2] << 16), acc[0][3] | (acc[1][3] << 16));
+    }
+    __syncthreads();
+    // ---- vertical pass: item = (output row, 4 adjacent columns)
+    for (int e = tid; e < GT_H * (GT_W / 4); e += 256) {
+        const int r = e >> 6, c4 = e & 63;
+        const int y = y0 + r, x = x0 + 4 * c4;
+        if (y >= h || x >= w) continue;
+        const bool odd = r & 1;
+        const int np = odd ? (T.ny + 2) >> 1 : (T.ny + 1) >> 1;  // pairs that hold taps
+        const u32* col = hz + (size_t)(r >> 1) * GT_W + 4 * c4;
+        u32 a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
+#pragma unroll
+        for (int j = 0; j < GT_G2; j++) {
+            if (j >= np) break;
+            const uint4 v = *(const uint4*)(col + (size_t)j * GT_W);
+            const gt_us2 k = __builtin_bit_cast(gt_us2, odd ? T.y2o[j] : T.y2e[j]);
+            a0 = __builtin_amdgcn_udot2(__builtin_bit_cast(gt_us2, v.x), k, a0, false);
+            a1 = __builtin_amdgcn_udot2(__builtin_bit_cast(gt_us2, v.y), k, a1, false);
+            a2 = __builtin_amdgcn_udot2(__builtin_bit_cast(gt_us2, v.z), k, a2, false);
+            a3 = __builtin_amdgcn_udot2(__builtin_bit_cast(gt_us2, v.w), k, a3, false);
+        }
+        *(u32*)(dst.row(b, y) + x) = (a0 >> 16) | ((a1 >> 16) << 8) | ((a2 >> 16) << 16) | ((a3 >> 16) << 24);
     }
 }
 
@@ -565,6 +723,33 @@ static int gaussian_impl(Plane s, Plane d, int width, int height, int batch, int
         const int v0 = kh == 3 ? 0 : ty.q8[0], v1 = ty.q8[kh == 3 ? 0 : 1], v2 = ty.q8[kh == 3 ? 1 : 2];
         hipLaunchKernelGGL(k_gauss5_stream, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, s, d, width, height, strips_x,
                            bands, (int)nwaves, border, x0, x1, x2, v0, v1, v2);
+        IPA_LAUNCH_CHECK();
+        return IPA_OK;
+    }
+    bool byte_taps = kw >= 3 && kh >= 3 && kw <= GT_MAX && kh <= GT_MAX;
+    for (int i = 0; i < kw && byte_taps; i++) byte_taps = tx.q8[i] >= 0 && tx.q8[i] <= 255;
+    for (int i = 0; i < kh && byte_taps; i++) byte_taps = ty.q8[i] >= 0 && ty.q8[i] <= 255;
+    if (g5 && byte_taps) {
+        // tiled two-pass kernel: both passes in LDS, no intermediate plane
+        const int tiles_x = cdiv(width, GT_W), tiles_y = cdiv(height, GT_H);
+        const long long blocks = (long long)tiles_x * tiles_y * batch;
+        IPA_REQUIRE(blocks < 0x7fffffffLL, IPA_ERR_ARG, "GaussianBlur: too many tiles");
+        GaussTileTaps T;
+        memset(&T, 0, sizeof(T));
+        T.nx = kw; T.ny = kh; T.border = border;
+        for (int i = 0; i < kw; i++) T.x4[i >> 2] |= (u32)tx.q8[i] << (8 * (i & 3));
+        for (int i = 0; i < kh; i++) {
+            T.y2e[i >> 1] |= (u32)ty.q8[i] << (16 * (i & 1));
+            T.y2o[(i + 1) >> 1] |= (u32)ty.q8[i] << (16 * ((i + 1) & 1));
+        }
+        const int SR = GT_H + 2 * (kh >> 1), SPW = (GT_W + 2 * (kw >> 1) + 3) / 4 + 2;
+        const size_t lds = (size_t)SR * SPW * 4 + (size_t)(SR / 2) * GT_W * 4;
+        static bool attr_set = false;
+        if (lds > 48 * 1024 && !attr_set) {
+            IPA_HIP(hipFuncSetAttribute((const void*)k_gauss_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_gauss_tile, dim3((unsigned)blocks), dim3(256), lds, st, s, d, width, height, tiles_x, tiles_y, T);
         IPA_LAUNCH_CHECK();
         return IPA_OK;
     }
