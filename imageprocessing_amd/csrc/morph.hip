@@ -804,6 +804,167 @@ __global__ __launch_bounds__(256) void k_morph_row_dbl(Plane src, Plane dst, int
     }
 }
 
+
+// ---- small 2-D kernels (each side at most 5 after folding the iterations), one pass, any gray levels --------
+// The layout of k_morph_row_dbl (a wave holds 1024 columns of a pair of rows, 16 columns per lane, the two rows in
+// the halves of a dword) walking down the image: the row direction is done per pair by doubling, the column
+// direction combines the last three pairs -- a window of at most five rows around a pair lies inside them --
+// with one byte permutation (which replicates a row into the halves that take part, 0xffff elsewhere) and one
+// packed min per source row.  An open / close runs as two such stages one pair apart.  Two-valued images need
+// no bit plane, no "is it binary" pass and no workspace on this path: 2 B/px of traffic.
+struct Small2DOp {
+    u32 sel[6];  // per source row (pair p-1 low/high, p low/high, p+1 low/high) used by BOTH rows of the pair: selector, else 0
+    int te, to;  // the source row only the even (te = 0..2) / only the odd (to = 3..5) output row uses
+    u32 sel_eo;  // selector that puts row te into the low and row to into the high half
+};
+
+// out = per-half minimum over the source rows of pairs A (p-1), B (p), C (p+1) selected by S
+__device__ __forceinline__ void s2d_vertical(const u32 (&A)[RD_COLS], const u32 (&B)[RD_COLS], const u32 (&C)[RD_COLS],
+                                             const Small2DOp& S, u32 (&out)[RD_COLS])
+{
+#pragma unroll
+    for (int i = 0; i < RD_COLS; i++) out[i] = 0xffffffffu;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        const u32 sel = S.sel[t];
+        if (sel) {  // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) {
+                const u32 x = t < 2 ? A[i] : (t < 4 ? B[i] : C[i]);
+                out[i] = pk_min16(out[i], __builtin_amdgcn_perm(x, x, sel));
+            }
+        }
+    }
+    // the first row of the even window and the last row of the odd window: one permutation for the two
+#pragma unroll
+    for (int te = 0; te < 3; te++)
+#pragma unroll
+        for (int to = 3; to < 6; to++)
+            if (S.te == te && S.to == to) {  // (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < RD_COLS; i++) {
+                    const u32 xe = te < 2 ? A[i] : B[i], xo = to < 4 ? B[i] : C[i];
+                    out[i] = pk_min16(out[i], __builtin_amdgcn_perm(xo, xe, S.sel_eo));
+                }
+            }
+}
+
+// selectors of one stage: output row r of pair p takes source rows r - ay .. r - ay + ky - 1
+static Small2DOp s2d_selectors(int ky, int ay)
+{
+    Small2DOp S;
+    for (int t = 0; t < 6; t++) {
+        const int d = t - 2;  // source row 2p + d
+        const bool even = d >= -ay && d <= ky - 1 - ay, odd = d >= 1 - ay && d <= ky - ay;
+        const u32 half = (t & 1) ? 0x0302u : 0x0100u;
+        S.sel[t] = (even && odd) ? ((half << 16) | half) : 0u;
+    }
+    S.te = 2 - ay;       // row 2p - ay: in the even window only
+    S.to = ky - ay + 2;  // row 2p + ky - ay: in the odd window only
+    S.sel_eo = (((S.to & 1) ? 0x0706u : 0x0504u) << 16) | ((S.te & 1) ? 0x0302u : 0x0100u);
+    return S;
+}
+
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_morph_small2d(Plane src, Plane dst, int w, int h, int strips, int bands, int useful,
+                                                       int first_dil, int kx, int ax, Small2DOp S, long long nwaves)
+{
+    constexpr int ITER = 36;                        // pairs a wave walks through (a multiple of 3)
+    constexpr int BP = NOPS == 1 ? ITER - 2 : ITER - 4;  // pairs of output rows per band
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_id >= nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const u32 wid = (u32)wave_id;
+    const u32 t1 = wid / (u32)strips;
+    const int sx = (int)(wid - t1 * (u32)strips);
+    const int b = (int)(t1 / (u32)bands), band = (int)(t1 - (u32)b * (u32)bands);
+    const int p0 = band * BP;  // first output pair
+    const int x0 = sx * useful - RD_COLS + RD_COLS * lane;  // one lane of halo on each side
+    const bool in_row = x0 >= 0 && x0 < w;
+    u32 inside = 0;
+    if (x0 + RD_COLS > 0 && x0 < w) {
+        const int lo = x0 < 0 ? -x0 : 0, hi = w - x0 < RD_COLS ? w - x0 : RD_COLS;
+        inside = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
+    const u8* const sbase = src.p + (size_t)b * src.stride + x0;
+    u8* const dbase = dst.p + (size_t)b * dst.stride + x0;
+    auto load_pair = [&](int p, uint4& ra, uint4& rb) {
+        ra = make_uint4(0, 0, 0, 0);
+        rb = make_uint4(0, 0, 0, 0);
+        const int y = 2 * p;
+        if (in_row && y >= 0 && y < h) ra = *(const uint4*)(sbase + (size_t)y * src.pitch);
+        if (in_row && y + 1 >= 0 && y + 1 < h) rb = *(const uint4*)(sbase + (size_t)(y + 1) * src.pitch);
+    };
+    // values of a stage's input outside the image -> identity; `dil`: the stage works on complemented bytes
+    auto mask_outside = [&](u32 (&m)[RD_COLS], int p) {
+        const u32 keep = ((2 * p >= 0 && 2 * p < h) ? 0x0000ffffu : 0u) | ((2 * p + 1 >= 0 && 2 * p + 1 < h) ? 0xffff0000u : 0u);
+#pragma unroll
+        for (int i = 0; i < RD_COLS; i++) m[i] = (inside >> i) & 1u ? ((m[i] & keep) | (0x00ff00ffu & ~keep)) : 0x00ff00ffu;
+    };
+    const bool dil1 = first_dil != 0, dil2 = !dil1;
+    u32 H1[3][RD_COLS], H2[NOPS == 2 ? 3 : 1][RD_COLS];
+    uint4 na, nb;
+    const int j0 = p0 - (NOPS == 1 ? 1 : 2);  // first pair loaded
+    load_pair(j0, na, nb);
+#pragma unroll 3
+    for (int it = 0; it < ITER; it++) {
+        const int j = j0 + it;
+        const uint4 ra = na, rb = nb;
+        load_pair(j + 1, na, nb);
+        u32 m[RD_COLS];
+        {
+            const u32 A[4] = {ra.x, ra.y, ra.z, ra.w}, B[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                m[4 * q + 0] = __builtin_amdgcn_perm(B[q], A[q], 0x0c040c00u);
+                m[4 * q + 1] = __builtin_amdgcn_perm(B[q], A[q], 0x0c050c01u);
+                m[4 * q + 2] = __builtin_amdgcn_perm(B[q], A[q], 0x0c060c02u);
+                m[4 * q + 3] = __builtin_amdgcn_perm(B[q], A[q], 0x0c070c03u);
+            }
+        }
+        if (dil1) {
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) m[i] ^= 0x00ff00ffu;
+        }
+        mask_outside(m, j);
+        if (kx > 1) rd_window_min(m, kx, ax);
+#pragma unroll
+        for (int i = 0; i < RD_COLS; i++) H1[it % 3][i] = m[i];
+        if (it < 2) continue;
+        // stage 1 of pair j - 1 from the row passes of pairs j - 2, j - 1, j
+        u32 e[RD_COLS];
+        s2d_vertical(H1[(it + 1) % 3], H1[(it + 2) % 3], H1[it % 3], S, e);
+        int po = j - 1;  // pair held by e
+        if (NOPS == 2) {
+            // second stage: the other kind of extremum, on stage 1's result
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) e[i] ^= 0x00ff00ffu;
+            mask_outside(e, j - 1);
+            if (kx > 1) rd_window_min(e, kx, ax);
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) H2[(it + 2) % 3][i] = e[i];
+            if (it < 4) continue;
+            s2d_vertical(H2[it % 3], H2[(it + 1) % 3], H2[(it + 2) % 3], S, e);
+            po = j - 2;
+        }
+        if ((NOPS == 2 ? dil2 : dil1)) {
+#pragma unroll
+            for (int i = 0; i < RD_COLS; i++) e[i] ^= 0x00ff00ffu;
+        }
+        const int y = 2 * po;
+        if (in_row && lane >= 1 && lane <= 62 && x0 < sx * useful + useful && po < p0 + BP && y < h) {
+            u32 oa[4], ob[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                oa[q] = __builtin_amdgcn_perm(e[4 * q + 1], e[4 * q], 0x0c0c0400u) | __builtin_amdgcn_perm(e[4 * q + 3], e[4 * q + 2], 0x04000c0cu);
+                ob[q] = __builtin_amdgcn_perm(e[4 * q + 1], e[4 * q], 0x0c0c0602u) | __builtin_amdgcn_perm(e[4 * q + 3], e[4 * q + 2], 0x06020c0cu);
+            }
+            *(uint4*)(dbase + (size_t)y * dst.pitch) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+            if (y + 1 < h) *(uint4*)(dbase + (size_t)(y + 1) * dst.pitch) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+        }
+    }
+}
+
 // Columns: van Herk / Gil-Werman.  The rows are cut into blocks of k; within a block P[i] is the
 // minimum from the block's first row to row i and S[i] the minimum from row i to its last row.  A
 // window of k rows that starts at row lo of block j is S_j[lo] and P_{j+1}[lo + k - 1]: three
@@ -1070,6 +1231,27 @@ static int launch_morph_row_dbl(Plane src, Plane dst, int w, int h, int batch, i
     return IPA_OK;
 }
 
+// Small 2-D kernels in one pass (k_morph_small2d).  Returns 1 when the shape is outside what the kernel covers.
+static int launch_morph_small2d(Plane src, Plane dst, int w, int h, int batch, int nops, int first_dil, int kx, int ky, int ax,
+                                int ay, hipStream_t st)
+{
+    if (ky < 2 || ky > 5 || kx > 7 || ay > 2 || ky - ay > 3) return 1;
+    if (nops * ax > RD_COLS || nops * (kx - 1 - ax) > RD_COLS) return 1;
+    const int useful = RD_WAVE - 2 * RD_COLS;
+    const int bp = nops == 1 ? 34 : 32;
+    const int strips = cdiv(w, useful), bands = cdiv(cdiv(h, 2), bp);
+    const long long nwaves = (long long)strips * bands * batch;
+    if (nwaves >= 0x7fffffffLL) return 1;
+    const Small2DOp S = s2d_selectors(ky, ay);
+    const dim3 grid((unsigned)((nwaves + 3) / 4));
+    if (nops == 1)
+        hipLaunchKernelGGL(k_morph_small2d<1>, grid, dim3(256), 0, st, src, dst, w, h, strips, bands, useful, first_dil, kx, ax, S, nwaves);
+    else
+        hipLaunchKernelGGL(k_morph_small2d<2>, grid, dim3(256), 0, st, src, dst, w, h, strips, bands, useful, first_dil, kx, ax, S, nwaves);
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
 static bool g_vhgw_attr_set = false;
 
 // One general 8-bit erode/dilate pass pair (rows then columns) with folded sizes.
@@ -1216,6 +1398,10 @@ IPA_EXPORT int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_str
     Plane t2 = mkplane(ar.take(tp * (size_t)height * batch), tp, tp * (size_t)height);
     const int nops = (op == IPA_MORPH_OPEN || op == IPA_MORPH_CLOSE) ? 2 : 1;
     const int first_dil = (op == IPA_MORPH_DILATE || op == IPA_MORPH_CLOSE) ? 1 : 0;
+    {   // small 2-D kernels: one pass over the bytes, two-valued or not
+        const int rc2 = launch_morph_small2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, st);
+        if (rc2 <= 0) return rc2;
+    }
     if (assume_binary) {
         int rc = launch_pack_bits(s, bits, bpw, bsw, width, height, batch, vmax, st);
         if (rc) return rc;
