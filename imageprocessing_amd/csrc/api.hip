@@ -360,12 +360,13 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
 int stage_gray(const Chunk& C, hipStream_t st)
 {
     ProfScope ps(PROF_GRAY_THRESH, st);
-    ClearList clr = {{nullptr, nullptr}, {0, 0}};
+    ClearList clr = {{nullptr, nullptr, nullptr}, {0, 0, 0}};
     if (C.precleared) {
         canny_flag_area(C.width, C.height, C.batch, C.canny_ws, &clr.p[0], &clr.n[0]);
         if (C.accum) {
             clr.p[1] = (u32*)C.point_counts;
             clr.n[1] = (u32)C.batch;
+            hough_rowcount_area(C.width, C.height, C.batch, C.max_points, C.hough_ws, &clr.p[2], &clr.n[2]);
         }
     }
     return launch_bgr2gray(C.B, C.G, C.T, C.bits, C.bpw, C.bsw, C.width, C.height, C.batch, C.tv, 255, 1, st, clr);
@@ -426,7 +427,8 @@ int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t s
     if (!C.accum) return IPA_OK;
     return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
                            C.point_counts, C.hough_ws, C.L.hough_bytes,
-                           (lists_ready || fused_points()) ? HOUGH_VOTE_ONLY : HOUGH_ALL, resident_wgs, st, C.precleared);
+                           fused_points() ? HOUGH_VOTE_ONLY_FOREIGN_LISTS : (lists_ready ? HOUGH_VOTE_ONLY : HOUGH_ALL), resident_wgs,
+                           st, C.precleared);
 }
 
 // Events that order the helper streams.  They come from a per-thread pool that lives as long as the

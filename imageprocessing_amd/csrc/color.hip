@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane b
                                                   size_t bpw, size_t bsw, int w, int h, int cpr, int ithresh,
                                                   u32 v_above, u32 v_below, ClearList clr)
 {
-    if (clr.n[0] | clr.n[1]) {  // (wave-uniform) the first workgroup zeroes the scratch of the stages that follow
+    if (clr.n[0] | clr.n[1] | clr.n[2]) {  // (wave-uniform) the first workgroup zeroes the scratch of the stages that follow
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
             const u32 t = threadIdx.y * 64 + threadIdx.x;
-            for (int a = 0; a < 2; a++)
+            for (int a = 0; a < 3; a++)
                 for (u32 i = t; i < clr.n[a]; i += 256) clr.p[a][i] = 0;
         }
     }
@@ -348,7 +348,7 @@ int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, siz
         else
             hipLaunchKernelGGL((k_bgr2gray<false, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
         IPA_LAUNCH_CHECK();
-        clr.n[0] = clr.n[1] = 0;  // (only the first launch clears)
+        clr.n[0] = clr.n[1] = clr.n[2] = 0;  // (only the first launch clears)
     }
     return IPA_OK;
 }

@@ -151,12 +151,12 @@ struct ProfScope {
 // Small scratch areas (sizes in dwords, 16-byte aligned starts) that the gray kernel zeroes on the side for the
 // stages behind it, so that a short pass does not spend launches on clearing a few kilobytes.
 struct ClearList {
-    u32* p[2];
-    u32 n[2];
+    u32* p[3];
+    u32 n[3];
 };
 int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bits_pitch_words, size_t bits_stride_words,
                     int w, int h, int batch, int ithresh, int maxval, int inv, hipStream_t st,
-                    ClearList clr = ClearList{{nullptr, nullptr}, {0, 0}});
+                    ClearList clr = ClearList{{nullptr, nullptr, nullptr}, {0, 0, 0}});
 
 // bit-plane geometry: words per row rounded to a multiple of 32 (one 128-byte cache line), so
 // that the 128-byte pieces the producing waves write never share a line between workgroups
@@ -215,7 +215,9 @@ int hough_segments(int numrho);
 // phase: which part of the accumulator stage to enqueue.  resident_wgs > 0: the vote kernel runs as that
 // many workgroups (one per CU, each looping over its share of the work) so that it keeps half of every
 // CU while a streaming kernel of another stream uses the rest.
-enum HoughPhase { HOUGH_ALL = 0, HOUGH_VOTE_ONLY = 1, HOUGH_COMPACT_ONLY = 2 };
+// HOUGH_VOTE_ONLY_FOREIGN_LISTS: the lists were not made by this file's compaction (no per-row counts exist)
+enum HoughPhase { HOUGH_ALL = 0, HOUGH_VOTE_ONLY = 1, HOUGH_COMPACT_ONLY = 2, HOUGH_VOTE_ONLY_FOREIGN_LISTS = 3 };
+void hough_rowcount_area(int w, int h, int batch, int max_points, void* ws, u32** p, u32* dwords);
 // counts_cleared: point_counts has been zeroed by the caller (on the same stream)
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
                     int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,

@@ -16,7 +16,9 @@
 #include "common.hpp"
 
 #include <math.h>
+#include <mutex>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -102,7 +104,8 @@ __device__ __forceinline__ u32 nonzero_bytes(u32 v) { return ((v | ((v & 0x7f7f7
 // queue up at the image's one counter.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_hough_compact2(Plane src, int w, int h, int cpr, u32* __restrict__ pts,
-                                                             size_t pts_stride, u32 cap, int32_t* __restrict__ counts, int spread)
+                                                             size_t pts_stride, u32 cap, int32_t* __restrict__ counts, int spread,
+                                                             int32_t* __restrict__ rowcnt, size_t rowcnt_stride)
 {
     __shared__ u32 s_pts[CP_STAGE];
     __shared__ u32 row_tot[NW * ROWS_PER_LANE];
@@ -147,6 +150,14 @@ __global__ __launch_bounds__(64 * NW) void k_hough_compact2(Plane src, int w, in
         total += t;
     }
     if (total == 0) return;  // uniform over the block
+    // non-zero pixels per image row (zeroed by the host): the vote takes the angles whose bin depends on the row
+    // alone from these counts instead of from the pixels
+    if (rowcnt && lane == 0 && y < h) {
+        u32 t = 0;
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_LANE; k++) t += row_tot[wave * ROWS_PER_LANE + k];
+        if (t) atomicAdd(&rowcnt[(size_t)b * rowcnt_stride + y], (int32_t)t);
+    }
     if (tid == 0) s_base = (u32)atomicAdd(&counts[b], (int32_t)total);
     u32* out = pts + (size_t)b * pts_stride;
     const bool staged = total <= (u32)CP_STAGE;
@@ -204,6 +215,11 @@ struct VoteArgs {
     int dbg_only_grp;   // experiments: only this angle group votes (-1 = all)
     u32 dbg_trip_mask;  // experiments: list trips wrapped into a small window (0xffffffff = off)
     u32 items;        // k_hough_vote_s: (image, angle group) work items = groups * images of the launch
+    // k_hough_vote_s: angles whose bin is the same for every pixel of an image row (bit n of rowdet: angle n; checked
+    // on the host for this image size): they are voted from the per-row pixel counts, one add per row
+    const int32_t* rowcnt;
+    size_t rowcnt_stride;
+    u32 rowdet[IPA_MAX_ANGLES / 32];
 };
 
 __device__ __forceinline__ int rho_index(float x, float y, float c, float s)
@@ -390,9 +406,11 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     float cg[TG], sg[TG];
     int col0[TG];
     u32 k4[TG];  // byte offset such that (float bits of r + 1.5*2^23) * 4 + k4 addresses the bin
+    bool byrow[TG];  // this angle is voted from the row counts
 #pragma unroll
     for (int g = 0; g < TG; g++) {
         const int n = min(n0 + g, A.numangle - 1);
+        byrow[g] = A.rowcnt != nullptr && ((A.rowdet[n >> 5] >> (n & 31)) & 1u) != 0;
         const float c = T.c[n], s = T.s[n];
         // smallest reachable rho: the float ops are monotone, so it lies at a corner
         const float xw = (float)(A.w - 1), yh = (float)(A.h - 1);
@@ -443,7 +461,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         const f2 y23 = {(float)(cur.z >> 16), (float)(cur.w >> 16)};
 #pragma unroll
         for (int g = 0; g < TG; g++) {
-            if (g < tg) {
+            if (g < tg && !byrow[g]) {  // (wave-uniform)
                 const f2 r01 = (x01 * cg[g] + y01 * sg[g]) + magic;  // every op rounds on its own
                 const f2 r23 = (x23 * cg[g] + y23 * sg[g]) + magic;
                 atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.x) << 2) + k4[g])), 1u);
@@ -478,7 +496,19 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
 #pragma unroll
         for (int g = 0; g < TG; g++)
-            if (g < tg) atomicAdd(&hist[g * span + rho_index(x, y, cg[g], sg[g]) + half + 1 - col0[g]], 1u);
+            if (g < tg && !byrow[g]) atomicAdd(&hist[g * span + rho_index(x, y, cg[g], sg[g]) + half + 1 - col0[g]], 1u);
+    }
+    // angles whose bin depends on the row alone: every row's pixel count goes to the bin of its first pixel
+    if (slice == 0) {
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+            if (g < tg && byrow[g]) {
+                const int32_t* rc = A.rowcnt + (size_t)b * A.rowcnt_stride;
+                for (int yy = tid; yy < A.h; yy += NT) {
+                    const u32 nrow = (u32)rc[yy];
+                    if (nrow) atomicAdd(&hist[g * span + rho_index(0.f, (float)yy, cg[g], sg[g]) + half + 1 - col0[g]], nrow);
+                }
+            }
     }
     __syncthreads();
 
@@ -671,6 +701,17 @@ void hough_dims(int w, int h, double rho, double theta, int* numangle, int* numr
 
 bool g_vote_attr_set = false;
 
+// the row-block compaction (default) also counts the pixels of every row
+bool compact_mode_rows()
+{
+    static int cmode = -1;  // IPA_COMPACT_MODE=0 selects the grid-stride kernel
+    if (cmode < 0) {
+        const char* e = getenv("IPA_COMPACT_MODE");
+        cmode = e ? atoi(e) : 1;
+    }
+    return cmode == 1;
+}
+
 }  // namespace
 
 IPA_EXPORT int ipa_hough_dims(int width, int height, double rho, double theta, int* numangle, int* numrho)
@@ -689,11 +730,60 @@ static u32 point_cap(int w, int h, int max_points)
     return (u32)(full > 0xffffffffLL ? 0xffffffffLL : full);
 }
 
+// per-image row counts behind the point lists
+static size_t rowcnt_stride_elems(int h) { return align_up((size_t)h * 4, 256) / 4; }
+
 size_t hough_ws_bytes(int w, int h, int batch, int max_points)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
-    return align_up((size_t)point_cap(w, h, max_points) * 4, 256) * (size_t)batch + 256;
+    return align_up((size_t)point_cap(w, h, max_points) * 4, 256) * (size_t)batch + rowcnt_stride_elems(h) * 4 * (size_t)batch + 256;
 }
+
+void hough_rowcount_area(int w, int h, int batch, int max_points, void* ws, u32** p, u32* dwords)
+{
+    *p = (u32*)((u8*)ws + align_up((size_t)point_cap(w, h, max_points) * 4, 256) * (size_t)batch);
+    *dwords = (u32)(rowcnt_stride_elems(h) * (size_t)batch);
+}
+
+namespace {
+// Angles for which every pixel of an image row falls into one bin: the float operations are monotone in x, so it is
+// enough that the first and the last pixel of every row agree.  (theta = 90 degrees: cos is 4e-8, and all pixels
+// of a long horizontal stroke would otherwise add to one LDS address, lane after lane.)
+struct RowDetCache {
+    int w = -1, h = -1, numangle = 0;
+    float c0 = 0, s0 = 0, c1 = 0, s1 = 0;
+    u32 mask[IPA_MAX_ANGLES / 32] = {};
+};
+void row_determined_angles(const Trig& T, int numangle, int w, int h, u32* mask)
+{
+    static std::mutex mu;
+    static RowDetCache cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const int last = numangle - 1;
+    if (cache.w == w && cache.h == h && cache.numangle == numangle && cache.c0 == T.c[1 % numangle] && cache.s0 == T.s[1 % numangle] &&
+        cache.c1 == T.c[last] && cache.s1 == T.s[last]) {
+        memcpy(mask, cache.mask, sizeof(cache.mask));
+        return;
+    }
+    memset(cache.mask, 0, sizeof(cache.mask));
+    const volatile float xw = (float)(w - 1);
+    for (int n = 0; n < numangle; n++) {
+        const volatile float c = T.c[n], s = T.s[n];
+        if (fabsf(c) * xw >= 0.75f) continue;
+        bool same = true;
+        for (int y = 0; y < h && same; y++) {
+            const volatile float ys = (float)y * s;
+            const volatile float xc = xw * c;
+            const volatile float a = 0.0f * c + ys, b2 = xc + ys;
+            same = nearbyintf(a) == nearbyintf(b2);
+        }
+        if (same) cache.mask[n >> 5] |= 1u << (n & 31);
+    }
+    cache.w = w; cache.h = h; cache.numangle = numangle;
+    cache.c0 = T.c[1 % numangle]; cache.s0 = T.s[1 % numangle]; cache.c1 = T.c[last]; cache.s1 = T.s[last];
+    memcpy(mask, cache.mask, sizeof(cache.mask));
+}
+}  // namespace
 
 PointSink hough_point_sink(int w, int h, int max_points, int32_t* point_counts, void* ws)
 {
@@ -743,6 +833,8 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
     const u32 cap = point_cap(w, h, max_points);
     const size_t pts_stride = align_up((size_t)cap * 4, 256) / 4;
     u32* pts = (u32*)ws;
+    int32_t* const rowcnt = (int32_t*)((u8*)ws + pts_stride * 4 * (size_t)batch);
+    const size_t rowcnt_stride = rowcnt_stride_elems(h);
 
     Trig T;
     {
@@ -759,15 +851,14 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
 #else
     const bool revote = false;
 #endif
-    if (phase != HOUGH_VOTE_ONLY && !revote) {
-        if (!counts_cleared) IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+    if (phase != HOUGH_VOTE_ONLY && phase != HOUGH_VOTE_ONLY_FOREIGN_LISTS && !revote) {
+        if (!counts_cleared) {
+            IPA_HIP(hipMemsetAsync(point_counts, 0, sizeof(int32_t) * (size_t)batch, st));
+            IPA_HIP(hipMemsetAsync(rowcnt, 0, rowcnt_stride * 4 * (size_t)batch, st));
+        }
         ProfScope ps(PROF_HOUGH_COMPACT, st);
         const int cpr = cdiv(w, 16);
-        static int cmode = -1;  // IPA_COMPACT_MODE=0 selects the grid-stride kernel
-        if (cmode < 0) {
-            const char* e = getenv("IPA_COMPACT_MODE");
-            cmode = e ? atoi(e) : 1;
-        }
+        const int cmode = compact_mode_rows() ? 1 : 0;  // IPA_COMPACT_MODE=0 selects the grid-stride kernel
         if (cmode == 1) {
             // The four rows of a block are gridDim.z apart.  An odd distance: rows a multiple of 32 apart
             // (any height that is a multiple of 128) put the bins of theta = 90 degrees of all four into
@@ -786,9 +877,11 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             }
             static const size_t pad = lds_pad_kib("IPA_PAD_COMPACT");
             if (nw == 16)
-                hipLaunchKernelGGL(k_hough_compact2<16>, grid, dim3(64, 16), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
+                hipLaunchKernelGGL(k_hough_compact2<16>, grid, dim3(64, 16), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread,
+                                   rowcnt, rowcnt_stride);
             else
-                hipLaunchKernelGGL(k_hough_compact2<4>, grid, rows_block(), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread);
+                hipLaunchKernelGGL(k_hough_compact2<4>, grid, rows_block(), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread,
+                                   rowcnt, rowcnt_stride);
             IPA_LAUNCH_CHECK();
         } else {
             IPA_REQUIRE((long long)cpr * h < 0x7fffffffLL - (1 << 22), IPA_ERR_ARG, "HoughLines: image too large");
@@ -908,6 +1001,20 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)(cells / 1024 < 2048 ? cells / 1024 + 1 : 2048), (unsigned)batch), dim3(256), 0, st,
                            accum, accum_stride, cells);
         IPA_LAUNCH_CHECK();
+    }
+    // angles voted from the row counts (only the kernels that know them, and only when this library's row-block
+    // compaction made the lists)
+    A.rowcnt = nullptr;
+    A.rowcnt_stride = rowcnt_stride;
+    memset(A.rowdet, 0, sizeof(A.rowdet));
+    static int byrow_env = -1;  // IPA_VOTE_BYROW=0: every angle from the pixels (A/B)
+    if (byrow_env < 0) {
+        const char* e = getenv("IPA_VOTE_BYROW");
+        byrow_env = e ? atoi(e) : 1;
+    }
+    if (tgs && byrow_env && phase != HOUGH_VOTE_ONLY_FOREIGN_LISTS && compact_mode_rows()) {
+        row_determined_angles(T, numangle, w, h, A.rowdet);
+        A.rowcnt = rowcnt;
     }
     A.segmax = (tgs && A.slices == 1) ? seg_max : nullptr;
     const bool segmax_after = seg_max && A.slices > 1;  // computed from the finished accumulator
