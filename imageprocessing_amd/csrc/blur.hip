@@ -452,71 +452,60 @@ __global__ __launch_bounds__(256) void k_adapt_col(Plane src, const u32* __restr
 }
 
 // ---- streaming adaptive threshold ---------------------------------------------------------
-// One wave walks a 256-pixel-wide strip downwards, lane = 4 adjacent pixels.  A lane reads its
-// own row window [x - R, x + 3 + R] (clamped: BORDER_REPLICATE) straight from memory, so no
-// data moves between lanes; the row-pass results of the last 2R + 1 rows live in a ring in
-// LDS that is private to the lane's columns (no barrier, no intermediate plane).  The float
-// path keeps the operation order of the two-pass kernels: taps accumulated left to right in
-// the row pass, symmetric pairs in the column pass, every multiply and add rounded on its own.
+// A workgroup of four waves walks a 256-pixel-wide strip downwards, lane = 4 adjacent pixels, wave j takes the
+// rows y0 + j, y0 + 4 + j, ...  A lane reads its own row window [x - R, x + 3 + R] (clamped: BORDER_REPLICATE)
+// straight from memory, so no data moves between lanes; the row-pass results of the last 2R + 8 rows live in
+// a ring in LDS shared by the four waves (one barrier per trip of four rows, no intermediate plane).  Sharing
+// the ring keeps sixteen waves on a CU for the 31-tap window.  The float path keeps the operation order of the
+// two-pass kernels: taps accumulated left to right in the row pass, symmetric pairs in the column pass, every
+// multiply and add rounded on its own.
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ u32 adapt_load_dword(const u8* row, int xk, int w)
-{
-    if (xk >= 0 && xk + 4 <= w) return *(const u32*)(row + xk);
-    u32 v = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) v |= (u32)row[min(max(xk + j, 0), w - 1)] << (8 * j);
-    return v;
-}
-
 template <int R, bool GAUSS>
-__global__ __launch_bounds__(256) void k_adapt_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
-                                                      int band_rows, int nwaves, TapsF T, double box_scale, int idelta,
-                                                      int inv, u32 maxv)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_adapt_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
+                                                      int band_rows, TapsF T, double box_scale, int idelta, int inv,
+                                                      u32 maxv)
 {
     constexpr int N = 2 * R + 1;           // taps
     constexpr int PAD = (R + 3) / 4 * 4;   // window start x - PAD, a multiple of 4 pixels
     constexpr int ND = (PAD + 4 + R + 3) / 4;  // dwords covering [x - PAD, x + 3 + R]
-    // ring rows: exactly N for small windows (LDS, hence occupancy, matters more than index
-    // arithmetic there), else a power of two so that a slot is a mask away
-    constexpr int SLOTS = N <= 16 ? N : (N <= 32 ? 32 : 64);
-    constexpr bool POW2 = (SLOTS & (SLOTS - 1)) == 0;
-    extern __shared__ __align__(16) u32 ring[];  // [4 waves][SLOTS rows][64 lanes][4]
+    // ring rows: the rows y - R .. y + 3 + R of the four output rows of a trip, and the four rows that are
+    // written for the next trip while slower waves still read
+    constexpr int SLOTS = N + 7;
+    extern __shared__ __align__(16) u32 ring[];  // [SLOTS rows][64 lanes][4]
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const u32 wid = blockIdx.x * 4u + (u32)wv;
-    if (wid >= (u32)nwaves) return;
     const int lane = threadIdx.x & 63;
-    const u32 t = wid / (u32)strips_x;
-    const int sx = (int)(wid - t * (u32)strips_x);
+    const u32 t = blockIdx.x / (u32)strips_x;
+    const int sx = (int)(blockIdx.x - t * (u32)strips_x);
     const int b = (int)(t / (u32)bands), band = (int)(t - (u32)b * (u32)bands);
     const int x = sx * 256 + 4 * lane;
     const int y0 = band * band_rows, y1 = min(y0 + band_rows, h);
-    uint4* const myring = (uint4*)ring + (size_t)wv * SLOTS * 64 + lane;  // slot s at myring[s * 64]
-    // Row r (r may lie outside the image: then it holds a copy of the nearest image row, which is
-    // BORDER_REPLICATE) lives in slot (r + 64) & (SLOTS - 1); the column pass never clamps.
-    auto slot = [&](int r) -> uint4* {
-        const int s = POW2 ? ((r + 64) & (SLOTS - 1)) : (r + 64 * SLOTS) % SLOTS;  // r >= -R > -64
-        return myring + s * 64;
-    };
-    // slot of row base + j for 0 <= j < SLOTS, given sb = slot index of row `base`
-    auto slot_rel = [&](int sb, int j) -> uint4* {
-        int s = sb + j;
-        if (POW2) s &= SLOTS - 1;
-        else if (s >= SLOTS) s -= SLOTS;
-        return myring + s * 64;
-    };
+    uint4* const myring = (uint4*)ring + lane;  // slot s at myring[s * 64]; row r lives in slot (r - (y0 - R)) mod SLOTS
     const bool live = x < w;
 
     // strips whose windows lie inside the row read plain dwords (wave-uniform choice)
     const bool interior = sx * 256 - PAD >= 0 && sx * 256 + 252 - PAD + 4 * ND <= w;
+    // Border strips: dword k of the window starts at pixel xk = x - PAD + 4k (a multiple of four).  It is read at
+    // the nearest dword inside the row (the dword that holds pixel w - 1 lies inside the pitch), and the bytes
+    // left of pixel 0 / right of pixel w - 1 are replaced by copies of that pixel.
     auto load_row = [&](int yy, u32 (&d)[ND]) {
         const u8* row = src.row(b, yy);
         if (interior) {
 #pragma unroll
             for (int k = 0; k < ND; k++) d[k] = *(const u32*)(row + (x - PAD + 4 * k));
         } else {
+            const u32 first = row[0] * 0x01010101u, lastp = row[w - 1] * 0x01010101u;
+            int xx = x;
+            asm volatile("" : "+v"(xx));  // the offsets and masks below are recomputed per row, not kept in registers
 #pragma unroll
-            for (int k = 0; k < ND; k++) d[k] = live ? adapt_load_dword(row, x - PAD + 4 * k, w) : 0u;
+            for (int k = 0; k < ND; k++) {
+                const int xk = xx - PAD + 4 * k;
+                const u32 v = *(const u32*)(row + min(max(xk, 0), (w - 1) & ~3));
+                // bytes xk + j with 0 <= xk + j <= w - 1 come from memory
+                const int over = xk + 3 - (w - 1);  // > 0: that many bytes lie right of the last pixel
+                u32 keep = xk < 0 ? 0u : (over <= 0 ? 0xffffffffu : (over >= 4 ? 0u : (0xffffffffu >> (8 * over))));
+                d[k] = (v & keep) | ((xk < 0 ? first : lastp) & ~keep);
+            }
         }
     };
     // row pass of one image row (window dwords `d`)
@@ -536,6 +525,7 @@ __global__ __launch_bounds__(256) void k_adapt_stream(Plane src, Plane dst, int 
                 const f2v p01 = {p[i], p[i + 1]}, p23 = {p[i + 2], p[i + 3]};
                 a01 = a01 + p01 * k;  // -ffp-contract=off: separate multiply and add
                 a23 = a23 + p23 * k;
+                if (N > 16 && (i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (keeps the byte conversions near their use)
             }
             out = make_uint4(__float_as_uint(a01.x), __float_as_uint(a01.y), __float_as_uint(a23.x), __float_as_uint(a23.y));
         } else {
@@ -552,78 +542,97 @@ __global__ __launch_bounds__(256) void k_adapt_stream(Plane src, Plane dst, int 
         }
         return out;
     };
+    auto clampy = [&](int r) { return min(max(r, 0), h - 1); };
 
-    uint4 last = make_uint4(0, 0, 0, 0);
-    int sb = 0;
-    for (int r = y0 - R, have = -1; r <= y0 + R; r++) {
-        const int rr = min(max(r, 0), h - 1);
-        if (rr != have) {
-            u32 d[ND];
-            load_row(rr, d);
-            last = row_pass(d);
-            have = rr;
-        }
-        *slot(r) = last;
-    }
-    // the window of the row pushed in the next trip is loaded one trip ahead
-    u32 dn[ND];
-    load_row(min(y0 + 1 + R, h - 1), dn);
-    for (int y = y0; y < y1; y++) {
-        if (y > y0) {
+    // rows y0 - R .. y0 + R + 3 (ring slots 0 .. 2R + 3), every fourth one by this wave; rows outside the image
+    // are copies of the nearest image row
+    {
+        u32 dn[ND];
+        load_row(clampy(y0 - R + wv), dn);
+        for (int k = wv; k < 2 * R + 4; k += 4) {
             u32 dc[ND];
 #pragma unroll
-            for (int k = 0; k < ND; k++) dc[k] = dn[k];
-            load_row(min(y + 1 + R, h - 1), dn);
-            if (y + R <= h - 1) last = row_pass(dc);
-            *slot(y + R) = last;
+            for (int q = 0; q < ND; q++) dc[q] = dn[q];
+            if (k + 4 < 2 * R + 4) load_row(clampy(y0 - R + k + 4), dn);
+            myring[k * 64] = row_pass(dc);
         }
-        // slot index of row y - R, advanced by one per trip
-        sb = y == y0 ? (POW2 ? ((y - R + 64) & (SLOTS - 1)) : (y - R + 64 * SLOTS) % SLOTS) : (sb + 1 == SLOTS ? 0 : sb + 1);
-        int mean[4];
-        if (GAUSS) {
-            const uint4 c = *slot_rel(sb, R);
-            const float kc = T.f[R];
-            f2v a01 = {__uint_as_float(c.x) * kc, __uint_as_float(c.y) * kc};
-            f2v a23 = {__uint_as_float(c.z) * kc, __uint_as_float(c.w) * kc};
+    }
+    const int trips = (y1 - y0 + 3) >> 2;
+    // the window of the row pushed in a trip and the source pixels compared in it are loaded one trip ahead
+    u32 dn[ND];
+    u32 svn = 0;
+    load_row(clampy(y0 + wv + 4 + R), dn);
+    if (live && y0 + wv < y1) svn = *(const u32*)(src.row(b, y0 + wv) + x);  // the dword lies inside the pitch
+    int sb = wv;  // slot of row y - R
+    for (int trip = 0; trip < trips; trip++) {
+        const int y = y0 + 4 * trip + wv;
+        u32 dc[ND];
 #pragma unroll
-            for (int i = 1; i <= R; i++) {
-                const uint4 lo = *slot_rel(sb, R - i), hi = *slot_rel(sb, R + i);
-                const float k = T.f[R + i];
-                const f2v s01 = {__uint_as_float(hi.x) + __uint_as_float(lo.x), __uint_as_float(hi.y) + __uint_as_float(lo.y)};
-                const f2v s23 = {__uint_as_float(hi.z) + __uint_as_float(lo.z), __uint_as_float(hi.w) + __uint_as_float(lo.w)};
-                a01 = a01 + s01 * k;
-                a23 = a23 + s23 * k;
+        for (int q = 0; q < ND; q++) dc[q] = dn[q];
+        const u32 sv = svn;
+        const bool push = y + 4 + R <= y1 - 1 + R + 3 && trip + 1 < trips;  // some wave reads that row in the next trip
+        if (trip + 1 < trips) {
+            load_row(clampy(y + 8 + R), dn);
+            if (live && y + 4 < y1) svn = *(const u32*)(src.row(b, y + 4) + x);
+        }
+        __syncthreads();  // rows up to y0 + 4 * trip + 3 + R are in the ring
+        auto slot_rel = [&](int j) -> uint4* {  // row y - R + j, 0 <= j < SLOTS
+            int s2 = sb + j;
+            if (s2 >= SLOTS) s2 -= SLOTS;
+            return myring + s2 * 64;
+        };
+        // row y + 4 + R for the next trip: its slot held row y - R - 4, which nobody reads any more
+        if (push) *slot_rel(N + 3) = row_pass(dc);
+        if (y < y1) {
+            int mean[4];
+            if (GAUSS) {
+                const uint4 c = *slot_rel(R);
+                const float kc = T.f[R];
+                f2v a01 = {__uint_as_float(c.x) * kc, __uint_as_float(c.y) * kc};
+                f2v a23 = {__uint_as_float(c.z) * kc, __uint_as_float(c.w) * kc};
+#pragma unroll
+                for (int i = 1; i <= R; i++) {
+                    const uint4 lo = *slot_rel(R - i), hi = *slot_rel(R + i);
+                    const float k = T.f[R + i];
+                    const f2v s01 = {__uint_as_float(hi.x) + __uint_as_float(lo.x), __uint_as_float(hi.y) + __uint_as_float(lo.y)};
+                    const f2v s23 = {__uint_as_float(hi.z) + __uint_as_float(lo.z), __uint_as_float(hi.w) + __uint_as_float(lo.w)};
+                    a01 = a01 + s01 * k;
+                    a23 = a23 + s23 * k;
+                    if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // at most eight ring rows in registers
+                }
+                const float av[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int v = __float2int_rn(av[q]);
+                    mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                }
+            } else {
+                u32 acc[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const uint4 a = *slot_rel(i);
+                    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int v = (int)rint((double)acc[q] * box_scale);
+                    mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                }
             }
-            const float av[4] = {a01.x, a01.y, a23.x, a23.y};
+            if (live) {
+                u32 o = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int v = __float2int_rn(av[q]);
-                mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
-            }
-        } else {
-            u32 acc[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = -R; i <= R; i++) {
-                const uint4 a = *slot_rel(sb, R + i);
-                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int v = (int)rint((double)acc[q] * box_scale);
-                mean[q] = v < 0 ? 0 : (v > 255 ? 255 : v);
+                for (int q = 0; q < 4; q++) {
+                    const int dlt = (int)((sv >> (8 * q)) & 0xffu) - mean[q];
+                    const bool on = inv ? (dlt <= -idelta) : (dlt > -idelta);
+                    o |= (on ? maxv : 0u) << (8 * q);
+                }
+                *(u32*)(dst.row(b, y) + x) = o;  // bytes past the width stay inside the pitch
             }
         }
-        if (live) {
-            const u32 sv = adapt_load_dword(src.row(b, y), x, w);
-            u32 o = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int dlt = (int)((sv >> (8 * q)) & 0xffu) - mean[q];
-                const bool on = inv ? (dlt <= -idelta) : (dlt > -idelta);
-                o |= (on ? maxv : 0u) << (8 * q);
-            }
-            *(u32*)(dst.row(b, y) + x) = o;  // bytes past the width stay inside the pitch
-        }
+        sb += 4;
+        if (sb >= SLOTS) sb -= SLOTS;
     }
 }
 
@@ -836,24 +845,31 @@ IPA_EXPORT int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, s
     }
     const int R = block_size / 2;
     if (astream && (R == 1 || R == 2 || R == 3 || R == 5 || R == 15)) {
-        const int band_rows = R <= 5 ? 64 : 128;
-        const int strips_x = cdiv(width, 256), bands = cdiv(height, band_rows);
-        const long long nwaves = (long long)strips_x * bands * batch;
-        IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "adaptiveThreshold: too many strips");
-        const size_t lds = (size_t)4 * (block_size <= 16 ? block_size : 32) * 64 * 16;  // ring slots: see the kernel
-        const dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+        // bands as tall as the launch allows (every band row-passes 2R + 4 rows before its first output row) while
+        // the chip still gets two rounds of workgroups (four fit a CU)
+        const int strips_x = cdiv(width, 256);
+        const int min_rows = R <= 5 ? 64 : 128;
+        const long long per_band = (long long)strips_x * batch;
+        const int max_bands = cdiv(height, min_rows);
+        const int bands0 = (int)std::max<long long>(1, std::min<long long>(max_bands, (2LL * 4 * 256 + per_band - 1) / per_band));
+        const int band_rows = (cdiv(height, bands0) + 3) & ~3;
+        const int bands = cdiv(height, band_rows);
+        const long long nwgs = per_band * bands;
+        IPA_REQUIRE(nwgs < 0x7fffffffLL, IPA_ERR_ARG, "adaptiveThreshold: too many strips");
+        const size_t lds = (size_t)(block_size + 7) * 64 * 16;  // ring slots: see the kernel
+        const dim3 grid((unsigned)nwgs), block(256);
 #define IPA_ADAPT(RR)                                                                                                    \
     do {                                                                                                                 \
         if (method == 1) {                                                                                               \
             IPA_HIP(hipFuncSetAttribute((const void*)k_adapt_stream<RR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                      \
             hipLaunchKernelGGL((k_adapt_stream<RR, true>), grid, block, lds, st, s, d, width, height, strips_x, bands,    \
-                               band_rows, (int)nwaves, T, box_scale, idelta, type, maxv);                                \
+                               band_rows, T, box_scale, idelta, type, maxv);                                             \
         } else {                                                                                                         \
             IPA_HIP(hipFuncSetAttribute((const void*)k_adapt_stream<RR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                      \
             hipLaunchKernelGGL((k_adapt_stream<RR, false>), grid, block, lds, st, s, d, width, height, strips_x, bands,   \
-                               band_rows, (int)nwaves, T, box_scale, idelta, type, maxv);                                \
+                               band_rows, T, box_scale, idelta, type, maxv);                                             \
         }                                                                                                                \
     } while (0)
         if (R == 1) IPA_ADAPT(1);
