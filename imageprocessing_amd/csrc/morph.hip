@@ -559,6 +559,168 @@ __global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits
     }
 }
 
+
+// ---- two-valued images: bytes in, bytes out, any rectangle up to 33 x 31, one pass, no bit plane in memory -------
+// The layout of k_bitmorph_v (a wave = 64 consecutive 32-pixel words of a strip of rows, walking down) fed from the
+// bytes: lane L reads 16-byte piece L of each of the wave's two KiB of a row (every load instruction covers a
+// whole KiB), turns its 32 bytes into 32 "non-zero" bits, and two lane moves hand every lane the word of its own
+// 32 pixels.  A stage erodes along the row on the words of the lane and its two neighbours (doubling, as in
+// k_bitmorph_h3; dilation = erosion of the complement, outside the image = ones) and along the column with the
+// bit-sliced run counter of k_bitmorph_v; an open / close runs two stages, the second on the first one's words.
+// Lanes 0 .. nops-1 and 64-nops .. 63 are halo.  The output value is the non-zero value of the image, picked up
+// from the first non-zero dword the wave meets (an output pixel can only be set when an input pixel of its window
+// was, and that one the wave has read).
+// CHECK: the image is not known to be two-valued.  Every byte is compared with {0, value}; the wave that meets a
+// third value sets flags[image] and stops, the others look at the flag every four rows; the caller runs the
+// gray-level kernel for the flagged images afterwards.
+__device__ __forceinline__ u32 lane_up1(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }    // from lane + 1
+__device__ __forceinline__ u32 lane_down1(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }  // from lane - 1
+__device__ __forceinline__ u32 bm_pack16(uint4 v)
+{
+    return pb_bytes_to_bits(pb_nonzero_bytes(v.x)) | (pb_bytes_to_bits(pb_nonzero_bytes(v.y)) << 4) |
+           (pb_bytes_to_bits(pb_nonzero_bytes(v.z)) << 8) | (pb_bytes_to_bits(pb_nonzero_bytes(v.w)) << 12);
+}
+// erosion along the row: out[p] = AND of in[p - ax .. p - ax + kx - 1] for the word x between L and R
+__device__ __forceinline__ u32 bm_erode_row(u32 L, u32 x, u32 R, int kx, int ax, int px)
+{
+    if (kx == 1) return x;
+    Win3 v;
+    v.a0 = L; v.a1 = x; v.a2 = R;
+#pragma unroll
+    for (int mm = 1; mm <= 32; mm <<= 1)  // px = 64 (kx = 64, 65) needs the whole-word step too
+        if (mm < px) v = comb3(v, look(v, mm, 0xffffffffu), false);
+    return look(v, -ax, 0xffffffffu).a1 & look(v, kx - px - ax, 0xffffffffu).a1;
+}
+
+template <int NS, bool CHECK>
+__global__ __launch_bounds__(256) void k_binmorph2d(Plane src, Plane dst, int w, int h, int strips_y, int strip_rows, int useful,
+                                                    int first_is_dilate, int nops, int kx, int ax, int px, int ky, int ay,
+                                                    int32_t* __restrict__ flags)
+{
+    __shared__ uint2 lut[256];
+    build_expand_lut(lut);
+    const int lane = threadIdx.x;
+    const int sidx = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (sidx >= strips_y) return;
+    const int j0 = (int)blockIdx.x * useful - nops;  // word of lane 0
+    const int j = j0 + lane;
+    const int rem = w - 32 * j;
+    const u32 wmask = (j < 0 || rem <= 0) ? 0u : (rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u));
+    const int xa = 32 * j0 + 16 * lane, xb = xa + 1024;  // first pixel of the lane's two pieces
+    const bool la = xa >= 0 && xa < w, lb = xb >= 0 && xb < w;
+    const int na = w - xa, nb = w - xb;  // pixels of the piece inside the image when it is the last one
+    const int below = ky - 1 - ay;
+    const int r0 = sidx * strip_rows, r1 = min(r0 + strip_rows, h);
+    const bool dil0 = first_is_dilate != 0;
+    const u8* const sbase = src.p + (size_t)b * src.stride;
+    // which halves of which lanes make up this lane's word, and which words this lane stores
+    const int src_lane = (2 * lane) & 63;
+    const bool hi_half = lane >= 32;
+    const int sh = (lane & 1) * 16;
+    const int wl_a = lane >> 1, wl_b = 32 + (lane >> 1);  // lanes whose words hold pieces L and 64 + L
+    const bool st_a = wl_a >= nops && wl_a < 64 - nops && xa < w, st_b = wl_b >= nops && wl_b < 64 - nops && xb < w;
+    u32 d1[NS], d2[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        d1[i] = ((ky >> i) & 1) ? 0xffffffffu : 0u;  // "no row seen yet"
+        d2[i] = d1[i];
+    }
+    u32 vmask = 0;  // the image's non-zero value in all four bytes, 0 = not met yet (wave-uniform)
+    const int lag1 = below, lag2 = nops == 2 ? below : 0;
+    const int y_first = r0 - nops * ay, y_last = r1 - 1 + lag1 + lag2;
+    bool stop = false;  // (wave-uniform)
+    auto bytes_of = [&](uint4 v, int n) -> uint4 {  // the piece with the bytes beyond the image width cleared
+        if (n >= 16) return v;
+        u32 d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int m = n - 4 * q;
+            d[q] = m >= 4 ? d[q] : (m <= 0 ? 0u : (d[q] & ((1u << (8 * m)) - 1u)));
+        }
+        return make_uint4(d[0], d[1], d[2], d[3]);
+    };
+    auto step = [&](int y, uint4 pa, uint4 pb) {  // y is the same in all lanes
+        u32 in1 = 0xffffffffu;
+        if (y >= 0 && y < h) {
+            pa = bytes_of(pa, na);
+            pb = bytes_of(pb, nb);
+            const u32 any = pa.x | pa.y | pa.z | pa.w | pb.x | pb.y | pb.z | pb.w;
+            if (vmask == 0) {
+                const unsigned long long nz = __ballot(any != 0);
+                if (nz) {
+                    u32 f = any | (any >> 16);
+                    f = (f | (f >> 8)) & 0xffu;
+                    vmask = (u32)__builtin_amdgcn_readlane((int)f, (int)__builtin_ctzll(nz)) * 0x01010101u;
+                }
+            }
+            if (CHECK) {
+                // every byte must be 0 or the value: d == (0xff in its non-zero bytes) & vmask
+                u32 bad = 0;
+                const u32 dd[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const u32 nzb = pb_nonzero_bytes(dd[q]);
+                    bad |= dd[q] ^ (((nzb << 8) - nzb) & vmask);
+                }
+                if (__any(bad != 0)) {
+                    if (lane == 0) atomicOr(&flags[b], 1);
+                    stop = true;
+                    return;
+                }
+            }
+            const u32 hw = bm_pack16(pa) | (bm_pack16(pb) << 16);
+            const u32 v0 = (u32)__shfl((int)hw, src_lane), v1 = (u32)__shfl((int)hw, src_lane + 1);
+            const u32 raw = hi_half ? ((v0 >> 16) | (v1 & 0xffff0000u)) : ((v0 & 0xffffu) | (v1 << 16));
+            const u32 x = ((dil0 ? ~raw : raw) & wmask) | ~wmask;
+            in1 = bm_erode_row(lane_down1(x), x, lane_up1(x), kx, ax, px);
+        }
+        const u32 full1 = ky == 1 ? in1 : run_update<NS>(d1, in1, ky);
+        const int c1 = y - lag1;
+        if (c1 < r0 - (nops == 2 ? ay : 0)) return;
+        const u32 s1 = dil0 ? ~full1 : full1;  // stage-1 result of row c1
+        u32 out;
+        int r;
+        if (nops == 1) {
+            out = s1;
+            r = c1;
+        } else {
+            const bool dil1 = !dil0;
+            u32 in2 = 0xffffffffu;
+            if (c1 >= 0 && c1 < h) {
+                const u32 x = ((dil1 ? ~s1 : s1) & wmask) | ~wmask;
+                in2 = bm_erode_row(lane_down1(x), x, lane_up1(x), kx, ax, px);
+            }
+            const u32 full2 = ky == 1 ? in2 : run_update<NS>(d2, in2, ky);
+            out = dil1 ? ~full2 : full2;
+            r = c1 - lag2;
+        }
+        if (r < r0 || r >= r1) return;
+        out &= wmask;
+        const u32 wa = (u32)__shfl((int)out, wl_a), wb = (u32)__shfl((int)out, wl_b);
+        u8* orow = dst.row(b, r);
+        if (st_a) expand16_lut(lut, (wa >> sh) & 0xffffu, vmask, orow + xa);
+        if (st_b) expand16_lut(lut, (wb >> sh) & 0xffffu, vmask, orow + xb);
+    };
+    // four rows per trip: their loads are all in flight before the first is consumed
+    for (int y = y_first; y <= y_last && !stop; y += 4) {
+        uint4 pa[4], pb[4];
+        int flag = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int yy = y + k;
+            const bool in_rows = yy >= 0 && yy < h && yy <= y_last;
+            pa[k] = pb[k] = make_uint4(0, 0, 0, 0);
+            if (la && in_rows) pa[k] = *(const uint4*)(sbase + (size_t)yy * src.pitch + xa);
+            if (lb && in_rows) pb[k] = *(const uint4*)(sbase + (size_t)yy * src.pitch + xb);
+        }
+        if (CHECK) flag = __hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (y + k <= y_last && !stop) step(y + k, pa[k], pb[k]);
+        if (CHECK && flag) stop = true;
+    }
+}
+
 // ------------------------------------------------------------------ general 8-bit
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -671,8 +833,6 @@ __device__ __forceinline__ u32 pk_min16(u32 a, u32 b)
 {
     return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(mus2, a), __builtin_bit_cast(mus2, b)));
 }
-__device__ __forceinline__ u32 lane_up1(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }    // from lane + 1
-__device__ __forceinline__ u32 lane_down1(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }  // from lane - 1
 
 constexpr int RD_COLS = 16;            // columns per lane
 constexpr int RD_WAVE = 64 * RD_COLS;  // columns per wave
@@ -867,7 +1027,8 @@ static Small2DOp s2d_selectors(int ky, int ay)
 
 template <int NOPS>
 __global__ __launch_bounds__(256) void k_morph_small2d(Plane src, Plane dst, int w, int h, int strips, int bands, int useful,
-                                                       int first_dil, int kx, int ax, Small2DOp S, long long nwaves)
+                                                       int first_dil, int kx, int ax, Small2DOp S, long long nwaves,
+                                                       const int32_t* __restrict__ gate)
 {
     constexpr int ITER = 36;                        // pairs a wave walks through (a multiple of 3)
     constexpr int BP = NOPS == 1 ? ITER - 2 : ITER - 4;  // pairs of output rows per band
@@ -878,6 +1039,7 @@ __global__ __launch_bounds__(256) void k_morph_small2d(Plane src, Plane dst, int
     const u32 t1 = wid / (u32)strips;
     const int sx = (int)(wid - t1 * (u32)strips);
     const int b = (int)(t1 / (u32)bands), band = (int)(t1 - (u32)b * (u32)bands);
+    if (gate && gate[b] == 0) return;  // only the images the two-valued kernel gave up on
     const int p0 = band * BP;  // first output pair
     const int x0 = sx * useful - RD_COLS + RD_COLS * lane;  // one lane of halo on each side
     const bool in_row = x0 >= 0 && x0 < w;
@@ -1232,11 +1394,15 @@ static int launch_morph_row_dbl(Plane src, Plane dst, int w, int h, int batch, i
 }
 
 // Small 2-D kernels in one pass (k_morph_small2d).  Returns 1 when the shape is outside what the kernel covers.
-static int launch_morph_small2d(Plane src, Plane dst, int w, int h, int batch, int nops, int first_dil, int kx, int ky, int ax,
-                                int ay, hipStream_t st)
+static bool small2d_covers(int nops, int kx, int ky, int ax, int ay)
 {
-    if (ky < 2 || ky > 5 || kx > 7 || ay > 2 || ky - ay > 3) return 1;
-    if (nops * ax > RD_COLS || nops * (kx - 1 - ax) > RD_COLS) return 1;
+    if (ky < 2 || ky > 5 || kx > 7 || ay > 2 || ky - ay > 3) return false;
+    return nops * ax <= RD_COLS && nops * (kx - 1 - ax) <= RD_COLS;
+}
+static int launch_morph_small2d(Plane src, Plane dst, int w, int h, int batch, int nops, int first_dil, int kx, int ky, int ax,
+                                int ay, const int32_t* gate, hipStream_t st)
+{
+    if (!small2d_covers(nops, kx, ky, ax, ay)) return 1;
     const int useful = RD_WAVE - 2 * RD_COLS;
     const int bp = nops == 1 ? 34 : 32;
     const int strips = cdiv(w, useful), bands = cdiv(cdiv(h, 2), bp);
@@ -1245,10 +1411,56 @@ static int launch_morph_small2d(Plane src, Plane dst, int w, int h, int batch, i
     const Small2DOp S = s2d_selectors(ky, ay);
     const dim3 grid((unsigned)((nwaves + 3) / 4));
     if (nops == 1)
-        hipLaunchKernelGGL(k_morph_small2d<1>, grid, dim3(256), 0, st, src, dst, w, h, strips, bands, useful, first_dil, kx, ax, S, nwaves);
+        hipLaunchKernelGGL(k_morph_small2d<1>, grid, dim3(256), 0, st, src, dst, w, h, strips, bands, useful, first_dil, kx, ax, S, nwaves, gate);
     else
-        hipLaunchKernelGGL(k_morph_small2d<2>, grid, dim3(256), 0, st, src, dst, w, h, strips, bands, useful, first_dil, kx, ax, S, nwaves);
+        hipLaunchKernelGGL(k_morph_small2d<2>, grid, dim3(256), 0, st, src, dst, w, h, strips, bands, useful, first_dil, kx, ax, S, nwaves, gate);
     IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+
+// Two-valued images in one pass over the bytes (k_binmorph2d).  flags != nullptr: the images are not known to be
+// two-valued; flags[b] (zeroed here) is set for those that are not, and their output is to be redone.
+// Returns 1 when the shape is outside what the kernel covers.
+static int launch_binmorph2d(Plane src, Plane dst, int w, int h, int batch, int nops, int first_dil, int kx, int ky, int ax,
+                             int ay, int32_t* flags, hipStream_t st)
+{
+    if (ax > 32 || kx - 1 - ax > 32 || ky > 31) return 1;
+    static int on = -1;  // IPA_BINMORPH=0: the bit-plane kernels / the gray-level kernels as before (A/B)
+    if (on < 0) {
+        const char* e = getenv("IPA_BINMORPH");
+        on = e ? atoi(e) : 1;
+    }
+    if (!on) return 1;
+    int px = 1;
+    while (px * 2 <= kx) px *= 2;
+    const int useful = 64 - 2 * nops, words = cdiv(w, 32);
+    const int strips_x = cdiv(words, useful);
+    // strips of 128 rows; shorter ones (every strip re-reads nops * (ky - 1) rows) while the launch has few waves
+    int strip_rows = 128;
+    while (strip_rows > 32 && (long long)strips_x * cdiv(h, strip_rows) * batch < 4096) strip_rows >>= 1;
+    const int strips_y = cdiv(h, strip_rows);
+    if (flags) IPA_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * (size_t)batch, st));
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        Plane sb = src, db = dst;
+        sb.p += (size_t)b0 * src.stride;
+        db.p += (size_t)b0 * dst.stride;
+        const dim3 grid((unsigned)strips_x, (unsigned)cdiv(strips_y, 4), (unsigned)nb);
+        int32_t* fb = flags ? flags + b0 : nullptr;
+#define IPA_BM(NS, CHK)                                                                                                     \
+    hipLaunchKernelGGL((k_binmorph2d<NS, CHK>), grid, rows_block(), 0, st, sb, db, w, h, strips_y, strip_rows, useful, first_dil, \
+                       nops, kx, ax, px, ky, ay, fb)
+        if (ky < 8) {
+            if (flags) IPA_BM(3, true);
+            else IPA_BM(3, false);
+        } else {
+            if (flags) IPA_BM(5, true);
+            else IPA_BM(5, false);
+        }
+#undef IPA_BM
+        IPA_LAUNCH_CHECK();
+    }
     return IPA_OK;
 }
 
@@ -1398,8 +1610,21 @@ IPA_EXPORT int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_str
     Plane t2 = mkplane(ar.take(tp * (size_t)height * batch), tp, tp * (size_t)height);
     const int nops = (op == IPA_MORPH_OPEN || op == IPA_MORPH_CLOSE) ? 2 : 1;
     const int first_dil = (op == IPA_MORPH_DILATE || op == IPA_MORPH_CLOSE) ? 1 : 0;
-    {   // small 2-D kernels: one pass over the bytes, two-valued or not
-        const int rc2 = launch_morph_small2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, st);
+    if (assume_binary) {  // two-valued by the caller's word: one pass over the bytes through bit words in registers
+        const int rcb = launch_binmorph2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, nullptr, st);
+        if (rcb <= 0) return rcb;
+    }
+    if (small2d_covers(nops, KX, KY, AX, AY)) {
+        // Small 2-D kernels on an image of unknown content: the two-valued kernel first, which gives up on an image as
+        // soon as it meets a third value, then the gray-level kernel for the images it gave up on (one pass over the
+        // bytes each; a thresholded plane costs the first, a gray image the second and a few rows of the first).
+        int32_t* gate = nullptr;
+        if (!assume_binary) {
+            const int rcb = launch_binmorph2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, vmax, st);
+            if (rcb < 0) return rcb;
+            if (rcb == 0) gate = vmax;
+        }
+        const int rc2 = launch_morph_small2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, gate, st);
         if (rc2 <= 0) return rc2;
     }
     if (assume_binary) {

@@ -224,6 +224,38 @@ def test_morph_gray_images(op, ks, it):
         assert np.array_equal(a, b), (op, ks, it, img.shape, int((a != b).sum()))
 
 
+@pytest.mark.parametrize("op,ks,it", [(3, (3, 3), 2), (2, (3, 3), 1), (0, (3, 3), 2), (1, (2, 2), 1), (3, (5, 3), 1)])
+@pytest.mark.parametrize("assume", [0, 1])
+def test_morph_small_kernels_on_a_mixed_batch(op, ks, it, assume):
+    # NewVersion2/img2UML.py:34-35 (close it=2, open it=1 with 3x3) as a batch through the C ABI: two-valued images take
+    # the one-pass bit-word kernel; with assume_binary=0 an image with a third value is handed to the gray-level
+    # kernel (image by image), whatever its neighbours in the batch hold
+    import torch
+    from imageprocessing_amd import _native
+    from imageprocessing_amd._device import DevImage, stream_ptr, upload, workspace
+
+    h, w = 150, 2200  # wider than one wave of the bit-word kernel (2048 pixels)
+    rng = np.random.default_rng(op * 10 + it)
+    a = (rng.random((h, w)) < 0.55).astype(np.uint8) * 255
+    late = a.copy()
+    late[h - 3, w - 5] = 7  # the third value sits in the last rows
+    stack = [a, rand_gray(4, h, w), (rng.random((h, w)) < 0.5).astype(np.uint8) * 200, late, np.zeros((h, w), np.uint8)]
+    if assume:
+        stack = [stack[0], stack[2], stack[4]]
+    imgs = np.stack(stack)
+    L = _native.lib()
+    s = upload(imgs, 1, batched=True)
+    d = DevImage.empty(len(stack), h, w, 1)
+    ws = workspace(L.ipa_morph_workspace_bytes(w, h, len(stack)))
+    rc = L.ipa_morph_u8(s.ptr, s.pitch, s.stride, d.ptr, d.pitch, d.stride, w, h, len(stack), op, ks[0], ks[1], -1, -1, it,
+                        assume, ws.data_ptr(), ws.numel(), stream_ptr())
+    assert rc == 0, _native.last_error()
+    got = d.to_numpy(False)
+    for i, img in enumerate(stack):
+        ref = fr.morphology_ex(img, op, ks, it)
+        assert np.array_equal(got[i], ref), (i, int((got[i] != ref).sum()))
+
+
 def test_erode_dilate_api_and_anchor():
     img = (np.random.default_rng(2).random((50, 60)) < 0.5).astype(np.uint8) * 255
     g = rand_gray(3, 50, 60)
