@@ -90,13 +90,15 @@ def _run_group(images, idx, thresh_val, vert_len, horiz_len, iterations, segment
         pin = torch.empty((n, h, w, 3), dtype=torch.uint8, pin_memory=True)
         np.stack([images[i] for i in idx], out=pin.numpy())
         dev_in = pin.to(_device._device(), non_blocking=True)
-        res = pipeline.front_end_batch(dev_in, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len,
-                                       iterations=iterations, hough=False, edges=False)
+        # the fused pass also leaves the two line masks as 1-bit planes, which is what the segment passes read
+        fe = pipeline.FrontEnd(n, h, w, thresh_val=thresh_val, vert_len=vert_len, horiz_len=horiz_len, iterations=iterations,
+                               hough=False, edges=False, line_bits=bool(segments))
+        fe.run(_device.upload(dev_in, 3, batched=True))
         back = torch.empty((4, n, h, w), dtype=torch.uint8, pin_memory=True)
-        for k, plane in enumerate((res.gray, res.thresh, res.vlines, res.hlines)):
-            back[k].copy_(plane, non_blocking=True)
-        vseg = pipeline.segments_batch(res.vlines) if segments else [None] * n
-        hseg = pipeline.segments_batch(res.hlines) if segments else [None] * n
+        for k in range(4):
+            back[k].copy_(fe.plane(k).valid(), non_blocking=True)
+        vseg = fe.line_segments(0) if segments else [None] * n
+        hseg = fe.line_segments(1) if segments else [None] * n
         stream.synchronize()
     host = back.numpy()
     return [(i, ParsedImage(images[i], host[0, k], host[1, k], host[2, k], host[3, k], vseg[k], hseg[k])) for k, i in enumerate(idx)]

@@ -306,6 +306,7 @@ struct Chunk {
     hipStream_t caller;  // the caller's stream (key of the helper streams)
     FrontWs L;
     u32* bits;
+    u32 *vbits, *hbits;  // the two line masks as bit planes too (or NULL)
     void *canny_ws, *hough_ws, *blur_ws;
     u8* blur_plane;
     size_t bpw, bsw;
@@ -343,6 +344,7 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
     C.blur_ws = ar.take(C.L.blur_ws_bytes);
     C.blur_plane = (u8*)ar.take(C.L.blur_plane_bytes);
     C.bpw = bits_pitch_words(width), C.bsw = C.bpw * (size_t)height;
+    C.vbits = C.hbits = nullptr;  // set by the caller when wanted
     C.tv = thresh_val < -1 ? -1 : (thresh_val > 256 ? 256 : thresh_val);
     // open with (1 x vert_len) and (horiz_len x 1), iterations folded into one larger kernel
     C.KV = vert_len + (iterations - 1) * (vert_len - 1), C.AV = (vert_len / 2) * iterations;
@@ -377,11 +379,11 @@ int stage_opens(const Chunk& C, hipStream_t st)
     int rc;
     {
         ProfScope ps(PROF_OPEN_V, st);
-        rc = launch_bitmorph(C.bits, C.bpw, C.bsw, C.V, C.width, C.height, C.batch, 0, 2, 1, C.KV, 0, C.AV, 255, nullptr, st);
+        rc = launch_bitmorph(C.bits, C.bpw, C.bsw, C.V, C.width, C.height, C.batch, 0, 2, 1, C.KV, 0, C.AV, 255, nullptr, st, C.vbits);
     }
     if (rc) return rc;
     ProfScope ps(PROF_OPEN_H, st);
-    return launch_bitmorph(C.bits, C.bpw, C.bsw, C.H, C.width, C.height, C.batch, 0, 2, C.KH, 1, C.AH, 0, 255, nullptr, st);
+    return launch_bitmorph(C.bits, C.bpw, C.bsw, C.H, C.width, C.height, C.batch, 0, 2, C.KH, 1, C.AH, 0, 255, nullptr, st, C.hbits);
 }
 
 bool fused_points()
@@ -502,12 +504,12 @@ static int front_end_chunk(const Chunk& C, hipStream_t st, hipEvent_t after_gray
     return rc;
 }
 
-IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
-                                uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch,
-                                size_t plane_stride, int32_t* accum, size_t accum_stride, int32_t* seg_max,
-                                int max_points, int32_t* point_counts, int width, int height, int batch, int thresh_val,
-                                int vert_len, int horiz_len, int iterations, double canny_lo, double canny_hi,
-                                int blur5x5, void* ws, size_t ws_bytes, void* stream)
+static int front_end_impl(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
+                          uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch,
+                          size_t plane_stride, int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                          int max_points, int32_t* point_counts, int width, int height, int batch, int thresh_val,
+                          int vert_len, int horiz_len, int iterations, double canny_lo, double canny_hi,
+                          int blur5x5, void* ws, size_t ws_bytes, void* stream, uint32_t* vlines_bits, uint32_t* hlines_bits)
 {
     IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
     if (width == 0 || height == 0 || batch == 0) return IPA_OK;
@@ -538,6 +540,8 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
         if (rc) return rc;
         C[c].dev = dev;
         C[c].caller = st;
+        C[c].vbits = vlines_bits ? vlines_bits + (size_t)lo * C[c].bsw : nullptr;
+        C[c].hbits = hlines_bits ? hlines_bits + (size_t)lo * C[c].bsw : nullptr;
         ws_off += wsc;
     }
     if (nk == 1) return front_end_chunk(C[0], st);
@@ -603,4 +607,33 @@ IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr
         }
     }
     return rc;
+}
+
+IPA_EXPORT int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
+                                uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch,
+                                size_t plane_stride, int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                                int max_points, int32_t* point_counts, int width, int height, int batch, int thresh_val,
+                                int vert_len, int horiz_len, int iterations, double canny_lo, double canny_hi,
+                                int blur5x5, void* ws, size_t ws_bytes, void* stream)
+{
+    return front_end_impl(bgr, bgr_pitch, bgr_stride, gray, thresh, vlines, hlines, edges, plane_pitch, plane_stride, accum,
+                          accum_stride, seg_max, max_points, point_counts, width, height, batch, thresh_val, vert_len, horiz_len,
+                          iterations, canny_lo, canny_hi, blur5x5, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+IPA_EXPORT size_t ipa_bits_pitch_words(int width) { return width > 0 ? bits_pitch_words(width) : 0; }
+
+IPA_EXPORT int ipa_front_end_bits_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride, uint8_t* gray,
+                                     uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges, size_t plane_pitch,
+                                     size_t plane_stride, int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                                     int max_points, int32_t* point_counts, int width, int height, int batch, int thresh_val,
+                                     int vert_len, int horiz_len, int iterations, double canny_lo, double canny_hi,
+                                     int blur5x5, void* ws, size_t ws_bytes, void* stream, uint32_t* vlines_bits,
+                                     uint32_t* hlines_bits)
+{
+    IPA_REQUIRE(((uintptr_t)vlines_bits & 15) == 0 && ((uintptr_t)hlines_bits & 15) == 0, IPA_ERR_ALIGN,
+                "front_end: bit planes must be 16-byte aligned");
+    return front_end_impl(bgr, bgr_pitch, bgr_stride, gray, thresh, vlines, hlines, edges, plane_pitch, plane_stride, accum,
+                          accum_stride, seg_max, max_points, point_counts, width, height, batch, thresh_val, vert_len, horiz_len,
+                          iterations, canny_lo, canny_hi, blur5x5, ws, ws_bytes, stream, vlines_bits, hlines_bits);
 }

@@ -189,7 +189,8 @@ static inline size_t bits_pitch_words(int w) { return align_up((size_t)cdiv(w, 3
 
 int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch, hipStream_t st);
 int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, int h, int batch, int first_is_dilate,
-                    int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st);
+                    int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st,
+                    u32* bits_out = nullptr);  // bits_out: the result also as a bit plane of the input's pitch
 int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batch, int is_dilate, int kx, int ky,
                          int ax, int ay, hipStream_t st);
 int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, hipStream_t st);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_pack_bits(Plane src, u32* __restrict__ 
     if (lane == 0 && wv == 0) {
         const u32 bm = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         // a stale read only costs a redundant atomic
-        if (bm && (u32)__builtin_nontemporal_load(&vmax[b]) < bm) atomicMax(&vmax[b], (int32_t)bm);
+        if (vmax && bm && (u32)__builtin_nontemporal_load(&vmax[b]) < bm) atomicMax(&vmax[b], (int32_t)bm);
     }
 }
 
@@ -380,7 +380,8 @@ __device__ __forceinline__ Win3 comb3(Win3 a, Win3 b, bool dil)
 template <int NOPS, int KX, int AX>
 __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
                                                      int w, int h, int first_is_dilate, int nops_rt, int kx_rt, int ax_rt,
-                                                     int px_rt, u32 value, const int32_t* __restrict__ value_dev)
+                                                     int px_rt, u32 value, const int32_t* __restrict__ value_dev,
+                                                     u32* __restrict__ bits_out)
 {
     __shared__ uint2 lut[256];
     build_expand_lut(lut);
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(256) void k_bitmorph_h3(const u32* __restrict__ bit
         // gaps (32 bytes per lane would leave every instruction half of each cache line).
         const int lane = threadIdx.x;
         const u32 r1 = v.a1 & m.a1;
+        if (bits_out && live) bits_out[(size_t)b * bsw + (size_t)y * bpw + j] = r1;  // the result as a bit plane too
         const u32 wa = (u32)__shfl((int)r1, lane >> 1), wb = (u32)__shfl((int)r1, 32 + (lane >> 1));
         const int sh = (lane & 1) * 16;
         const int xa = blockIdx.x * 2048 + lane * 16, xb = xa + 1024;  // first pixel of each piece
@@ -483,7 +485,8 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits, size_t bpw, size_t bsw, Plane dst,
                                                     int w, int h, int words, int strips, int strip_rows,
                                                     int first_is_dilate, int nops, int ky, int ay,
-                                                    u32 value, const int32_t* __restrict__ value_dev)
+                                                    u32 value, const int32_t* __restrict__ value_dev,
+                                                    u32* __restrict__ bits_out)
 {
     __shared__ uint2 lut[256];
     build_expand_lut(lut);
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(256) void k_bitmorph_v(const u32* __restrict__ bits
         }
         if (r < r0 || r >= r1) return;
         out &= wmask;
+        if (bits_out && live) bits_out[(size_t)b * bsw + (size_t)r * bpw + j] = out;  // the result as a bit plane too
         const u32 wa = (u32)__shfl((int)out, lane >> 1), wb = (u32)__shfl((int)out, 32 + (lane >> 1));
         u8* orow = dst.row(b, r);
         if (xa < w) expand16_lut(lut, (wa >> sh) & 0xffffu, vmask, orow + xa);
@@ -1260,13 +1264,13 @@ int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h,
 {
     int cpr = cdiv(w, 16);
     cpr += cpr & 1;
-    IPA_HIP(hipMemsetAsync(vmax, 0, sizeof(int32_t) * (size_t)batch, st));
+    if (vmax) IPA_HIP(hipMemsetAsync(vmax, 0, sizeof(int32_t) * (size_t)batch, st));  // (NULL: the bits only)
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         Plane sb = src;
         sb.p += (size_t)b0 * src.stride;
         hipLaunchKernelGGL(k_pack_bits, rows_grid(cpr, h, nb), rows_block(), 0, st, sb, bits + (size_t)b0 * bsw, bpw, bsw, w, h,
-                           cpr, vmax + b0);
+                           cpr, vmax ? vmax + b0 : nullptr);
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;
@@ -1275,7 +1279,8 @@ int launch_pack_bits(Plane src, u32* bits, size_t bpw, size_t bsw, int w, int h,
 // Bit-plane morphology of `nops` stages (1: erode or dilate, 2: open or close)
 // with folded kernel kx x ky and folded anchor (ax, ay).
 int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, int h, int batch, int first_is_dilate,
-                    int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st)
+                    int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st,
+                    u32* bits_out)
 {
     static int fast = -1;  // IPA_BITMORPH_FAST=0 forces the LDS tile kernel
     if (fast < 0) {
@@ -1292,7 +1297,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
 #define IPA_H3(N, K, A)                                                                                          \
     hipLaunchKernelGGL((k_bitmorph_h3<N, K, A>), rows_grid(words, h, nb), rows_block(), morph_pad, st, bits + (size_t)b0 * bsw, \
                        bpw, bsw, db, w, h, first_is_dilate, nops, kx, ax, pow2_floor(kx), (u32)value,                   \
-                       value_dev ? value_dev + b0 : nullptr)
+                       value_dev ? value_dev + b0 : nullptr, bits_out ? bits_out + (size_t)b0 * bsw : nullptr)
             // the shapes of the parsers (15-pixel lines, 1 or 2 iterations) and of 3x3 open / close
             if (nops == 2 && kx == 29 && ax == 14) IPA_H3(2, 29, 14);
             else if (nops == 2 && kx == 15 && ax == 7) IPA_H3(2, 15, 7);
@@ -1319,11 +1324,11 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
             if (ky < 32)
                 hipLaunchKernelGGL(k_bitmorph_v<5>, grid, block, morph_pad, st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
                                    strips, strip_rows, first_is_dilate, nops, ky, ay, (u32)value,
-                                   value_dev ? value_dev + b0 : nullptr);
+                                   value_dev ? value_dev + b0 : nullptr, bits_out ? bits_out + (size_t)b0 * bsw : nullptr);
             else
                 hipLaunchKernelGGL(k_bitmorph_v<8>, grid, block, 0, st, bits + (size_t)b0 * bsw, bpw, bsw, db, w, h, words,
                                    strips, strip_rows, first_is_dilate, nops, ky, ay, (u32)value,
-                                   value_dev ? value_dev + b0 : nullptr);
+                                   value_dev ? value_dev + b0 : nullptr, bits_out ? bits_out + (size_t)b0 * bsw : nullptr);
             IPA_LAUNCH_CHECK();
         }
         return IPA_OK;
@@ -1373,6 +1378,8 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
     }
     hipLaunchKernelGGL(k_bitmorph, dim3((unsigned)blocks), dim3(256), lds, st, A);
     IPA_LAUNCH_CHECK();
+    // (the tile kernel writes bytes only: its result is packed again when the caller wants the bit plane)
+    if (bits_out) return launch_pack_bits(dst, bits_out, bpw, bsw, w, h, batch, nullptr, st);
     return IPA_OK;
 }
 

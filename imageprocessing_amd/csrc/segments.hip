@@ -346,29 +346,12 @@ IPA_EXPORT size_t ipa_segments_workspace_bytes(int width, int height, int batch,
     return a.off + 256;
 }
 
-IPA_EXPORT int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t mask_stride, int width, int height, int batch,
-                               int max_segments, int32_t* boxes, int max_boxes, int32_t* counts, void* ws, size_t ws_bytes,
-                               void* stream)
+namespace {
+// the passes behind the bit plane; `bits` is read only
+int segments_from_bits(const u32* bits, size_t bpw, size_t bsw, int width, int height, int batch, int max_segments,
+                       int32_t* boxes, int max_boxes, int32_t* counts, Arena& ar, hipStream_t st)
 {
-    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0 && max_boxes >= 0, IPA_ERR_ARG, "segments: negative size");
-    if (batch == 0) return IPA_OK;
-    IPA_REQUIRE(counts != nullptr && (boxes != nullptr || max_boxes == 0), IPA_ERR_ARG, "segments: NULL output");
-    hipStream_t st = (hipStream_t)stream;
-    if (width == 0 || height == 0) {
-        IPA_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)batch, st));
-        return IPA_OK;
-    }
-    IPA_REQUIRE(width <= 65535 && height <= 65535, IPA_ERR_ARG, "segments: image larger than 65535 pixels on a side");
-    Plane s = mkplane(mask, mask_pitch, mask_stride);
-    IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
-                "segments: pointer/pitch must be 16-byte aligned and pitch >= row bytes");
-    IPA_REQUIRE(ws && ws_bytes >= ipa_segments_workspace_bytes(width, height, batch, max_segments), IPA_ERR_WORKSPACE,
-                "segments: workspace too small");
     const u32 cap = seg_capacity(width, height, max_segments);
-    const size_t bpw = bits_pitch_words(width), bsw = bpw * (size_t)height;
-    Arena ar(ws, ws_bytes);
-    u32* bits = (u32*)ar.take(bpw * 4 * (size_t)height * batch);
-    int32_t* vmax = (int32_t*)ar.take(sizeof(int32_t) * (size_t)batch);
     SegArrays A;
     A.rowcnt = (u32*)ar.take(sizeof(u32) * (size_t)height * batch);
     A.rowoff = (u32*)ar.take(sizeof(u32) * ((size_t)height + 1) * batch);
@@ -381,8 +364,6 @@ IPA_EXPORT int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t ma
     A.flags = (u32*)ar.take(sizeof(u32) * (size_t)cap * batch);
     A.total = (int32_t*)ar.take(sizeof(int32_t) * (size_t)batch);
     A.cap = cap;
-    int rc = launch_pack_bits(s, bits, bpw, bsw, width, height, batch, vmax, st);
-    if (rc) return rc;
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         SegArrays B = A;
@@ -406,4 +387,55 @@ IPA_EXPORT int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t ma
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;
+}
+}  // namespace
+
+IPA_EXPORT int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t mask_stride, int width, int height, int batch,
+                               int max_segments, int32_t* boxes, int max_boxes, int32_t* counts, void* ws, size_t ws_bytes,
+                               void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0 && max_boxes >= 0, IPA_ERR_ARG, "segments: negative size");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(counts != nullptr && (boxes != nullptr || max_boxes == 0), IPA_ERR_ARG, "segments: NULL output");
+    hipStream_t st = (hipStream_t)stream;
+    if (width == 0 || height == 0) {
+        IPA_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)batch, st));
+        return IPA_OK;
+    }
+    IPA_REQUIRE(width <= 65535 && height <= 65535, IPA_ERR_ARG, "segments: image larger than 65535 pixels on a side");
+    Plane s = mkplane(mask, mask_pitch, mask_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch), IPA_ERR_ALIGN,
+                "segments: pointer/pitch must be 16-byte aligned and pitch >= row bytes");
+    IPA_REQUIRE(ws && ws_bytes >= ipa_segments_workspace_bytes(width, height, batch, max_segments), IPA_ERR_WORKSPACE,
+                "segments: workspace too small");
+    const size_t bpw = bits_pitch_words(width), bsw = bpw * (size_t)height;
+    Arena ar(ws, ws_bytes);
+    u32* bits = (u32*)ar.take(bpw * 4 * (size_t)height * batch);
+    int32_t* vmax = (int32_t*)ar.take(sizeof(int32_t) * (size_t)batch);
+    int rc = launch_pack_bits(s, bits, bpw, bsw, width, height, batch, vmax, st);
+    if (rc) return rc;
+    return segments_from_bits(bits, bpw, bsw, width, height, batch, max_segments, boxes, max_boxes, counts, ar, st);
+}
+
+IPA_EXPORT int ipa_segments_bits_u32(const uint32_t* bits, size_t bits_pitch_words_, size_t bits_stride_words, int width,
+                                     int height, int batch, int max_segments, int32_t* boxes, int max_boxes, int32_t* counts,
+                                     void* ws, size_t ws_bytes, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0 && max_boxes >= 0, IPA_ERR_ARG, "segments: negative size");
+    if (batch == 0) return IPA_OK;
+    IPA_REQUIRE(counts != nullptr && (boxes != nullptr || max_boxes == 0), IPA_ERR_ARG, "segments: NULL output");
+    hipStream_t st = (hipStream_t)stream;
+    if (width == 0 || height == 0) {
+        IPA_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)batch, st));
+        return IPA_OK;
+    }
+    IPA_REQUIRE(width <= 65535 && height <= 65535, IPA_ERR_ARG, "segments: image larger than 65535 pixels on a side");
+    IPA_REQUIRE(bits != nullptr && ((uintptr_t)bits & 3) == 0 && bits_pitch_words_ >= (size_t)cdiv(width, 32) &&
+                    (batch == 1 || bits_stride_words >= bits_pitch_words_ * (size_t)height),
+                IPA_ERR_ALIGN, "segments: bit plane pointer / pitch / stride");
+    IPA_REQUIRE(ws && ws_bytes >= ipa_segments_workspace_bytes(width, height, batch, max_segments), IPA_ERR_WORKSPACE,
+                "segments: workspace too small");
+    Arena ar(ws, ws_bytes);
+    return segments_from_bits(bits, bits_pitch_words_, bits_stride_words, width, height, batch, max_segments, boxes, max_boxes,
+                              counts, ar, st);
 }

@@ -53,7 +53,7 @@ class FrontEnd:
 
     def __init__(self, batch: int, height: int, width: int, *, thresh_val: int = 128, vert_len: int = 15,
                  horiz_len: int = 15, iterations: int = 2, canny=(50, 150), blur: bool = False, hough: bool = True,
-                 max_points: int = 0, edges: bool = True):
+                 max_points: int = 0, edges: bool = True, line_bits: bool = False):
         L = _native.lib()
         self.batch, self.height, self.width = int(batch), int(height), int(width)
         self.thresh_val, self.vert_len, self.horiz_len = int(thresh_val), int(vert_len), int(horiz_len)
@@ -77,6 +77,10 @@ class FrontEnd:
             self.accum = None
             self.point_counts = None
             self.seg_max = None
+        # line_bits: the two line masks also as 1-bit planes, the form get_segments works on (line_segments())
+        self.bits_pitch = int(L.ipa_bits_pitch_words(self.width))
+        self.line_bits = (torch.empty((2, max(self.batch, 1), max(self.height, 1), self.bits_pitch), dtype=torch.int32, device=dev)
+                          if line_bits else None)
         self._unchecked = False
         self._alloc_ws()
 
@@ -97,7 +101,7 @@ class FrontEnd:
         if (bgr.batch, bgr.height, bgr.width, bgr.channels) != (self.batch, self.height, self.width, 3):
             raise error("front_end: input batch does not match the planned shape")
         p = [self.plane(k) for k in range(5)]
-        check(L.ipa_front_end_u8(
+        args = (
             bgr.ptr, bgr.pitch, bgr.stride, p[0].ptr, p[1].ptr, p[2].ptr, p[3].ptr, p[4].ptr if self.edges else None,
             p[0].pitch, p[0].stride,
             self.accum.data_ptr() if self.hough else None, self.accum.stride(0) if self.hough else 0,
@@ -105,8 +109,19 @@ class FrontEnd:
             self.max_points if self.hough else 1, self.point_counts.data_ptr() if self.hough else None,
             self.width, self.height, self.batch, self.thresh_val, self.vert_len, self.horiz_len, self.iterations,
             float(self.canny[0]), float(self.canny[1]), 1 if self.blur else 0,
-            self.ws.data_ptr(), self.ws.numel(), stream_ptr()))
+            self.ws.data_ptr(), self.ws.numel(), stream_ptr())
+        if self.line_bits is not None:
+            check(L.ipa_front_end_bits_u8(*args, self.line_bits[0].data_ptr(), self.line_bits[1].data_ptr()))
+        else:
+            check(L.ipa_front_end_u8(*args))
         self._unchecked = self.hough and self.max_points < self.height * self.width
+
+    def line_segments(self, which: int, max_boxes: int = 4096):
+        """get_segments (umlClassdiagram.py:33-36) of the vertical (which = 0) or horizontal (1) line masks of
+        the last pass, from their 1-bit planes (FrontEnd(..., line_bits=True)): per image a list of (x, y, w, h)."""
+        if self.line_bits is None:
+            raise error("front_end: plan the FrontEnd with line_bits=True")
+        return _segments_run(self.batch, self.height, self.width, max_boxes, bits=self.line_bits[which], bits_pitch=self.bits_pitch)
 
     def check_overflow(self) -> bool:
         """True when an image of the last ``enqueue`` had more edge pixels than ``max_points``: its
@@ -223,32 +238,41 @@ def rebinarize(img, rects, thresh_val=128, bg_color=(255, 255, 255), maxval=255,
     return to(s), to(g), to(t)
 
 
-def segments_batch(masks, max_boxes=4096):
-    """get_segments of the parsers for a batch of masks uint8[N,H,W] (numpy or ROCm tensor):
-    per image the list of (x, y, w, h) of cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
-    + cv2.boundingRect, in cv2's order (umlClassdiagram.py:33-36)."""
+def _segments_run(n, height, width, max_boxes, mask: DevImage = None, bits=None, bits_pitch=0):
+    """The segment pass on byte masks (``mask``) or on 1-bit planes int32[n, height, bits_pitch] (``bits``)."""
     L = _native.lib()
-    s = upload(masks, 1, batched=True)
-    n = s.batch
     if n == 0:
         return []
-    dev = s.t.device
+    dev = mask.t.device if mask is not None else bits.device
     max_segments = 0
     while True:
         boxes = torch.empty((n, max(max_boxes, 1), 4), dtype=torch.int32, device=dev)
         counts = torch.zeros(n, dtype=torch.int32, device=dev)
-        ws = workspace(L.ipa_segments_workspace_bytes(s.width, s.height, n, max_segments))
-        check(L.ipa_segments_u8(s.ptr, s.pitch, s.stride, s.width, s.height, n, max_segments, boxes.data_ptr(), max_boxes,
-                                counts.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()))
+        ws = workspace(L.ipa_segments_workspace_bytes(width, height, n, max_segments))
+        if mask is not None:
+            check(L.ipa_segments_u8(mask.ptr, mask.pitch, mask.stride, width, height, n, max_segments, boxes.data_ptr(),
+                                    max_boxes, counts.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()))
+        else:
+            check(L.ipa_segments_bits_u32(bits.data_ptr(), bits_pitch, bits_pitch * height, width, height, n, max_segments,
+                                          boxes.data_ptr(), max_boxes, counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          stream_ptr()))
         c = counts.cpu().numpy()
         if (c < 0).any():  # more runs than planned for: allow every pixel to be its own run
-            max_segments = s.width * s.height
+            max_segments = width * height
             continue
         if c.max(initial=0) > max_boxes:
             max_boxes = int(c.max())
             continue
         b = boxes.cpu().numpy()
         return [[tuple(int(v) for v in b[i, k]) for k in range(int(c[i]))] for i in range(n)]
+
+
+def segments_batch(masks, max_boxes=4096):
+    """get_segments of the parsers for a batch of masks uint8[N,H,W] (numpy or ROCm tensor):
+    per image the list of (x, y, w, h) of cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
+    + cv2.boundingRect, in cv2's order (umlClassdiagram.py:33-36)."""
+    s = upload(masks, 1, batched=True)
+    return _segments_run(s.batch, s.height, s.width, max_boxes, mask=s)
 
 
 def get_segments(lines, max_boxes=4096):

@@ -370,6 +370,31 @@ int ipa_front_end_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
                      double canny_lo, double canny_hi, int blur5x5,
                      void* ws, size_t ws_bytes, void* stream);
 
+
+/* ipa_front_end_u8 that also leaves the two line masks as 1-bit planes (bit i of word j of a row = pixel
+ * 32 j + i is set), the form get_segments works on: extract_lines followed by get_segments on both masks
+ * (umlClassdiagram.py:27-36, umlSequencediagram.py:30-39, umlActivitydiagram.py:41-50,
+ * umlStateDiagram.py:27-36) then needs no pass that packs the byte masks again.  Rows are
+ * ipa_bits_pitch_words(width) words apart, images height rows apart; 16-byte aligned; either may be NULL. */
+size_t ipa_bits_pitch_words(int width);
+int ipa_front_end_bits_u8(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride,
+                          uint8_t* gray, uint8_t* thresh, uint8_t* vlines, uint8_t* hlines, uint8_t* edges,
+                          size_t plane_pitch, size_t plane_stride,
+                          int32_t* accum, size_t accum_stride, int32_t* seg_max,
+                          int max_points, int32_t* point_counts,
+                          int width, int height, int batch,
+                          int thresh_val, int vert_len, int horiz_len, int iterations,
+                          double canny_lo, double canny_hi, int blur5x5,
+                          void* ws, size_t ws_bytes, void* stream,
+                          uint32_t* vlines_bits, uint32_t* hlines_bits);
+
+/* ipa_segments_u8 on a mask that already is a 1-bit plane (as written by ipa_front_end_bits_u8; bits beyond the
+ * width must be clear): get_segments of the parsers, umlClassdiagram.py:33-36.  Same outputs and workspace. */
+int ipa_segments_bits_u32(const uint32_t* bits, size_t bits_pitch_words, size_t bits_stride_words,
+                          int width, int height, int batch, int max_segments,
+                          int32_t* boxes, int max_boxes, int32_t* counts,
+                          void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

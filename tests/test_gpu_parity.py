@@ -256,6 +256,36 @@ def test_morph_small_kernels_on_a_mixed_batch(op, ks, it, assume):
         assert np.array_equal(got[i], ref), (i, int((got[i] != ref).sum()))
 
 
+@pytest.mark.parametrize("lines,chunks", [(15, 0), (15, 3), (101, 0), (6, 0)])
+def test_front_end_line_bit_planes_feed_get_segments(lines, chunks):
+    # extract_lines followed by get_segments on both masks (umlClassdiagram.py:27-36): the fused pass hands the
+    # segment pass the 1-bit planes of the two opens; same rectangles as from the byte masks and as the oracle's
+    import torch
+    import imageprocessing_amd as ipa
+    from imageprocessing_amd import pipeline
+    from imageprocessing_amd._device import upload
+
+    n, h, w = 7, 210, 470
+    imgs = np.stack([uml_like(60 + i, h, w) for i in range(n)])
+    fe = ipa.FrontEnd(n, h, w, thresh_val=128, vert_len=lines, horiz_len=lines, iterations=2, hough=False, edges=False,
+                      line_bits=True)
+    fe.line_bits.fill_(-1)  # stale bits must not survive
+    if chunks:
+        pipeline.set_option("pipeline_chunks", chunks)
+    try:
+        fe.run(upload(imgs, 3, batched=True))
+    finally:
+        pipeline.set_option("pipeline_chunks", -1)
+    for which, k in ((0, 2), (1, 3)):
+        mask = fe.plane(k).to_numpy(False)
+        got = fe.line_segments(which)
+        assert got == pipeline.segments_batch(torch.from_numpy(mask).cuda())
+        for i in range(n):
+            ref = fr.front_end(imgs[i], 128, lines, 2, 50, 150)[k]
+            assert np.array_equal(mask[i], ref)
+            assert got[i] == [tuple(int(v) for v in r) for r in fr.external_boxes(ref)], (which, i)
+
+
 def test_erode_dilate_api_and_anchor():
     img = (np.random.default_rng(2).random((50, 60)) < 0.5).astype(np.uint8) * 255
     g = rand_gray(3, 50, 60)
