@@ -192,7 +192,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
                     int nops, int kx, int ky, int ax, int ay, int value, const int32_t* value_dev, hipStream_t st,
                     u32* bits_out = nullptr);  // bits_out: the result also as a bit plane of the input's pitch
 int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batch, int is_dilate, int kx, int ky,
-                         int ax, int ay, hipStream_t st);
+                         int ax, int ay, hipStream_t st, const int32_t* gate = nullptr);  // gate[b] == 0: image b is skipped
 int launch_gauss5(Plane src, Plane dst, int w, int h, int batch, hipStream_t st);
 
 // Per-image lists of edge pixels (y << 16 | x), appended to by the Canny kernels when the

@@ -744,13 +744,14 @@ __device__ __forceinline__ u32 minmax4(u32 a, u32 b, bool dil)
 // Row pass: a workgroup owns 1024 consecutive pixels of one row; the segment and
 // its halo sit in LDS as bytes; each lane produces 4 adjacent outputs.
 __global__ __launch_bounds__(256) void k_morph_row(Plane src, Plane dst, int w, int h, int segs, int k, int a,
-                                                   int dil)
+                                                   int dil, const int32_t* __restrict__ gate)
 {
     extern __shared__ __align__(16) u8 srow[];
     int blk = blockIdx.x;
     const int sx = blk % segs;
     blk /= segs;
     const int y = blk % h, b = blk / h;
+    if (gate && gate[b] == 0) return;  // (gate: only the images flagged by the two-valued kernel)
     const int x0 = sx * 1024;
     const int L = (a + 3) & ~3, R = (k - 1 - a + 3) & ~3;
     const int n = 1024 + L + R;  // bytes in LDS, multiple of 4
@@ -795,13 +796,14 @@ __global__ __launch_bounds__(256) void k_morph_row(Plane src, Plane dst, int w, 
 
 // Column pass: one lane = 4 adjacent columns (one dword) x 4 output rows.
 __global__ __launch_bounds__(256) void k_morph_col(Plane src, Plane dst, int w, int h, int dwords, int rowgroups, int k,
-                                                   int a, int dil, long long total)
+                                                   int a, int dil, long long total, const int32_t* __restrict__ gate)
 {
     const long long step = (long long)gridDim.x * blockDim.x;
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += step) {
         int dx = (int)(c % dwords);
         long long t = c / dwords;
         int rg = (int)(t % rowgroups), b = (int)(t / rowgroups);
+        if (gate && gate[b] == 0) continue;
         const int y0 = rg * 4;
         const u32 ident = dil ? 0u : 0xffffffffu;
         u32 o[4] = {ident, ident, ident, ident};
@@ -904,7 +906,8 @@ __device__ __forceinline__ void rd_window_min(u32 (&m)[RD_COLS], int k, int a)
 // One wave = one pair of rows x one strip of `useful` output columns (+ halo).  nops = 1 (erode or
 // dilate) or 2 (open / close, second stage of the other kind).  halo_l is a multiple of 16.
 __global__ __launch_bounds__(256) void k_morph_row_dbl(Plane src, Plane dst, int w, int h, int strips, int pairs, int useful,
-                                                       int halo_l, int nops, int first_dil, int k, int a, long long nwaves)
+                                                       int halo_l, int nops, int first_dil, int k, int a, long long nwaves,
+                                                       const int32_t* __restrict__ gate)
 {
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wave_id >= nwaves) return;
@@ -913,6 +916,7 @@ __global__ __launch_bounds__(256) void k_morph_row_dbl(Plane src, Plane dst, int
     const u32 t1 = wid / (u32)strips;
     const int sx = (int)(wid - t1 * (u32)strips);
     const int b = (int)(t1 / (u32)pairs), rp = (int)(t1 - (u32)b * (u32)pairs);
+    if (gate && gate[b] == 0) return;
     const int y = 2 * rp;
     const int x0 = sx * useful - halo_l + RD_COLS * lane;  // first column of this lane (a multiple of 16)
     const bool in_row = x0 >= 0 && x0 < w;
@@ -1160,7 +1164,7 @@ __device__ __forceinline__ void bytes_minmax_acc(u32& acc, u32 v)
 
 template <bool DIL>
 __global__ __launch_bounds__(64) void k_morph_col_vhgw(Plane src, Plane dst, int w, int h, int dwords, int strips, int bands,
-                                                       int band_rows, int k, int a)
+                                                       int band_rows, int k, int a, const int32_t* __restrict__ gate)
 {
     extern __shared__ u32 ring[];  // [k][64]
     const int lane = threadIdx.x;
@@ -1168,6 +1172,7 @@ __global__ __launch_bounds__(64) void k_morph_col_vhgw(Plane src, Plane dst, int
     const int sx = blk % strips;
     blk /= strips;
     const int band = blk % bands, b = blk / bands;
+    if (gate && gate[b] == 0) return;
     const int dx = sx * 64 + lane;
     const bool live = dx < dwords;
     const int Y0 = band * band_rows, Y1 = min(Y0 + band_rows, h);
@@ -1386,7 +1391,7 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
 // Row pass in registers (k_morph_row_dbl): nops stages with the same kernel length kx and anchor ax.
 // Returns 1 when the shape is outside what the kernel covers (the caller then uses k_morph_row).
 static int launch_morph_row_dbl(Plane src, Plane dst, int w, int h, int batch, int nops, int first_dil, int kx, int ax,
-                                hipStream_t st)
+                                hipStream_t st, const int32_t* gate = nullptr)
 {
     const int halo_l = (int)align_up((size_t)(nops * ax), 16), halo_r = nops * (kx - 1 - ax);
     const int useful = (RD_WAVE - halo_l - halo_r) & ~15;
@@ -1395,7 +1400,7 @@ static int launch_morph_row_dbl(Plane src, Plane dst, int w, int h, int batch, i
     const long long nwaves = (long long)strips * pairs * batch;
     if (nwaves >= 0x7fffffffLL) return 1;
     hipLaunchKernelGGL(k_morph_row_dbl, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, src, dst, w, h, strips, pairs, useful,
-                       halo_l, nops, first_dil, kx, ax, nwaves);
+                       halo_l, nops, first_dil, kx, ax, nwaves, gate);
     IPA_LAUNCH_CHECK();
     return IPA_OK;
 }
@@ -1475,12 +1480,12 @@ static bool g_vhgw_attr_set = false;
 
 // One general 8-bit erode/dilate pass pair (rows then columns) with folded sizes.
 int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batch, int is_dilate, int kx, int ky,
-                         int ax, int ay, hipStream_t st)
+                         int ax, int ay, hipStream_t st, const int32_t* gate)
 {
     Plane cur = src;
     if (kx > 1) {
         Plane out = ky > 1 ? tmp : dst;
-        int rc = launch_morph_row_dbl(cur, out, w, h, batch, 1, is_dilate, kx, ax, st);
+        int rc = launch_morph_row_dbl(cur, out, w, h, batch, 1, is_dilate, kx, ax, st, gate);
         if (rc < 0) return rc;
         if (rc == 1) {
             int segs = cdiv(w, 1024);
@@ -1492,7 +1497,7 @@ int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batc
             }
             long long blocks = (long long)segs * h * batch;
             hipLaunchKernelGGL(k_morph_row, dim3((unsigned)blocks), dim3(256), lds, st, cur, out, w, h, segs, kx, ax,
-                               is_dilate);
+                               is_dilate, gate);
             IPA_LAUNCH_CHECK();
         }
         cur = out;
@@ -1519,16 +1524,16 @@ int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batc
             }
             if (is_dilate)
                 hipLaunchKernelGGL(k_morph_col_vhgw<true>, dim3((unsigned)blocks), dim3(64), lds, st, cur, dst, w, h, dwords, strips, bands,
-                                   band_rows, ky, ay);
+                                   band_rows, ky, ay, gate);
             else
                 hipLaunchKernelGGL(k_morph_col_vhgw<false>, dim3((unsigned)blocks), dim3(64), lds, st, cur, dst, w, h, dwords, strips, bands,
-                                   band_rows, ky, ay);
+                                   band_rows, ky, ay, gate);
             IPA_LAUNCH_CHECK();
         } else {
             int rowgroups = cdiv(h, 4);
             long long total = (long long)dwords * rowgroups * batch;
             hipLaunchKernelGGL(k_morph_col, dim3(stream_grid(total, 256)), dim3(256), 0, st, cur, dst, w, h, dwords,
-                               rowgroups, ky, ay, is_dilate, total);
+                               rowgroups, ky, ay, is_dilate, total, gate);
             IPA_LAUNCH_CHECK();
         }
         cur = dst;
@@ -1617,34 +1622,32 @@ IPA_EXPORT int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_str
     Plane t2 = mkplane(ar.take(tp * (size_t)height * batch), tp, tp * (size_t)height);
     const int nops = (op == IPA_MORPH_OPEN || op == IPA_MORPH_CLOSE) ? 2 : 1;
     const int first_dil = (op == IPA_MORPH_DILATE || op == IPA_MORPH_CLOSE) ? 1 : 0;
-    if (assume_binary) {  // two-valued by the caller's word: one pass over the bytes through bit words in registers
-        const int rcb = launch_binmorph2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, nullptr, st);
-        if (rcb <= 0) return rcb;
+    // Two-valued images (every call of the reference): one pass over the bytes through bit words in registers.
+    // assume_binary: by the caller's word.  Otherwise the same kernel checks what it reads, gives up on an image
+    // as soon as it meets a third value and flags it; the gray-level kernels below then run for the flagged images
+    // only (they read the flags).  A thresholded plane costs one pass, a gray image the gray-level passes and the
+    // few rows the first kernel read.
+    const int32_t* gate = nullptr;
+    {
+        const int rcb = launch_binmorph2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, assume_binary ? nullptr : vmax, st);
+        if (rcb < 0 || (rcb == 0 && assume_binary)) return rcb;
+        if (rcb == 0) gate = vmax;
     }
-    if (small2d_covers(nops, KX, KY, AX, AY)) {
-        // Small 2-D kernels on an image of unknown content: the two-valued kernel first, which gives up on an image as
-        // soon as it meets a third value, then the gray-level kernel for the images it gave up on (one pass over the
-        // bytes each; a thresholded plane costs the first, a gray image the second and a few rows of the first).
-        int32_t* gate = nullptr;
-        if (!assume_binary) {
-            const int rcb = launch_binmorph2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, vmax, st);
-            if (rcb < 0) return rcb;
-            if (rcb == 0) gate = vmax;
-        }
+    {   // small 2-D kernels: one pass over the bytes
         const int rc2 = launch_morph_small2d(s, d, width, height, batch, nops, first_dil, KX, KY, AX, AY, gate, st);
         if (rc2 <= 0) return rc2;
     }
-    if (assume_binary) {
+    if (assume_binary) {  // (rectangles beyond what the one-pass kernel covers)
         int rc = launch_pack_bits(s, bits, bpw, bsw, width, height, batch, vmax, st);
         if (rc) return rc;
         return launch_bitmorph(bits, bpw, bsw, d, width, height, batch, first_dil, nops, KX, KY, AX, AY, 0, vmax, st);
     }
-    if (nops == 1) return launch_morph_generic(s, d, t1, width, height, batch, first_dil, KX, KY, AX, AY, st);
+    if (nops == 1) return launch_morph_generic(s, d, t1, width, height, batch, first_dil, KX, KY, AX, AY, st, gate);
     if (KY == 1) {  // open / close along the rows only: both stages in one pass over the registers
-        const int rc1 = launch_morph_row_dbl(s, d, width, height, batch, 2, first_dil, KX, AX, st);
+        const int rc1 = launch_morph_row_dbl(s, d, width, height, batch, 2, first_dil, KX, AX, st, gate);
         if (rc1 <= 0) return rc1;
     }
-    int rc = launch_morph_generic(s, t2, t1, width, height, batch, first_dil, KX, KY, AX, AY, st);
+    int rc = launch_morph_generic(s, t2, t1, width, height, batch, first_dil, KX, KY, AX, AY, st, gate);
     if (rc) return rc;
-    return launch_morph_generic(t2, d, t1, width, height, batch, !first_dil, KX, KY, AX, AY, st);
+    return launch_morph_generic(t2, d, t1, width, height, batch, !first_dil, KX, KY, AX, AY, st, gate);
 }

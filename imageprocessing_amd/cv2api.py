@@ -206,15 +206,15 @@ def _morph(src, op, kernel, anchor, iterations, borderType, borderValue):
     s = upload(src, 1)
     d = DevImage.empty(1, s.height, s.width, 1)
     ws = workspace(L.ipa_morph_workspace_bytes(s.width, s.height, 1))
-    # Small 2-D kernels run in one pass over the bytes whatever the image holds; for the others two-valued
-    # images (thresholded planes) take the bit-plane kernels, which is worth a pass that looks at the pixels.
+    # Content unknown (assume_binary = 0): the library tries its one-pass kernel for two-valued images first, which
+    # gives up on an image as soon as it meets a third value, and runs the gray-level kernels only then.
+    # Rectangles beyond what that kernel covers (longer than 65 or higher than 31 after folding the iterations):
+    # two-valued images take the bit-plane kernels, which is worth a pass that looks at the pixels.
     n = max(int(iterations), 1)
     fx, fy = kw + (n - 1) * (kw - 1), kh + (n - 1) * (kh - 1)
-    cx, cy = (ax if ax >= 0 else kw // 2) * n, (ay if ay >= 0 else kh // 2) * n
-    nops = 2 if op in (MORPH_OPEN, MORPH_CLOSE) else 1
-    one_pass = 2 <= fy <= 5 and fx <= 7 and cy <= 2 and fy - cy <= 3 and nops * cx <= 16 and nops * (fx - 1 - cx) <= 16
+    cx = (ax if ax >= 0 else kw // 2) * n
     binary = 0
-    if not one_pass:
+    if cx > 32 or fx - 1 - cx > 32 or fy > 31:
         flags = torch.zeros(1, dtype=torch.int32, device=s.t.device)
         check(L.ipa_binary_check_u8(s.ptr, s.pitch, s.stride, s.width, s.height, 1, flags.data_ptr(), stream_ptr()))
         binary = 1 if int(flags.item()) >= 0 else 0

@@ -202,11 +202,10 @@ int ipa_gaussian_blur_u8(const uint8_t* src, size_t src_pitch, size_t src_stride
  * anchor (-1,-1) = kernel centre.  `assume_binary` != 0 promises that every
  * pixel is 0 or one common non-zero value and selects the kernels that work on
  * one bit per pixel (for rectangles up to 33 x 31 after folding the iterations:
- * one pass, bytes in, bytes out).  0 = content unknown: the general 8-bit
- * kernels; for the small rectangles of the reference's 3x3 calls (sides up to
- * 5 after folding) the one-bit kernel runs first, gives up on an image as soon
- * as it meets a third value, and the 8-bit kernel redoes only those images.
- * Results do not depend on the choice when the promise holds. */
+ * one pass, bytes in, bytes out).  0 = content unknown: the one-bit kernel
+ * runs first (for the rectangles it covers), gives up on an image as soon as
+ * it meets a third value, and the general 8-bit kernels redo only those
+ * images.  Results do not depend on the choice when the promise holds. */
 size_t ipa_morph_workspace_bytes(int width, int height, int batch);
 int ipa_morph_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
                  uint8_t* dst, size_t dst_pitch, size_t dst_stride,

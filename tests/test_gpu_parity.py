@@ -224,7 +224,8 @@ def test_morph_gray_images(op, ks, it):
         assert np.array_equal(a, b), (op, ks, it, img.shape, int((a != b).sum()))
 
 
-@pytest.mark.parametrize("op,ks,it", [(3, (3, 3), 2), (2, (3, 3), 1), (0, (3, 3), 2), (1, (2, 2), 1), (3, (5, 3), 1)])
+@pytest.mark.parametrize("op,ks,it", [(3, (3, 3), 2), (2, (3, 3), 1), (0, (3, 3), 2), (1, (2, 2), 1), (3, (5, 3), 1),
+                                      (2, (15, 1), 2), (2, (1, 15), 2), (3, (9, 9), 1), (0, (33, 16), 2)])
 @pytest.mark.parametrize("assume", [0, 1])
 def test_morph_small_kernels_on_a_mixed_batch(op, ks, it, assume):
     # NewVersion2/img2UML.py:34-35 (close it=2, open it=1 with 3x3) as a batch through the C ABI: two-valued images take
