@@ -287,6 +287,23 @@ def test_front_end_line_bit_planes_feed_get_segments(lines, chunks):
             assert got[i] == [tuple(int(v) for v in r) for r in fr.external_boxes(ref)], (which, i)
 
 
+@pytest.mark.parametrize("w", [1, 31, 32, 33, 64, 65, 1919, 1920, 1921, 1984, 1985, 2048, 2049, 3969])
+def test_morph_two_valued_one_pass_kernel_at_word_and_wave_boundaries(w):
+    # widths around the 32-pixel words and the 60 / 62 useful words of a wave of the one-pass two-valued kernel,
+    # heights around its strips, the widest rectangle it takes (65 x 31), anchors off centre
+    rng = np.random.default_rng(w)
+    for h, ks, it, anchor in [(1, (3, 3), 1, None), (3, (65, 31), 1, None), (37, (5, 4), 2, (0, 3)), (130, (2, 31), 1, (1, 0)),
+                              (33, (33, 2), 2, (32, 0))]:
+        img = (rng.random((h, w)) < 0.7).astype(np.uint8) * 255
+        if ks[0] > 2 * w + 40:
+            continue
+        k = np.ones((ks[1], ks[0]), np.uint8)
+        for op in (0, 1, 2, 3):
+            a = cv2.morphologyEx(img, op, k, anchor=anchor if anchor else (-1, -1), iterations=it)
+            b = fr.morphology_ex(img, op, ks, it, anchor if anchor else (-1, -1))
+            assert np.array_equal(a, b), (w, h, ks, it, anchor, op, int((a != b).sum()))
+
+
 def test_erode_dilate_api_and_anchor():
     img = (np.random.default_rng(2).random((50, 60)) < 0.5).astype(np.uint8) * 255
     g = rand_gray(3, 50, 60)
