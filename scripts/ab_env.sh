@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of environment settings on the headline batch.  usage: scripts/ab_env.sh "VAR=a VAR=b ..." (one bench run per word)
+set -u
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+i=0
+for kv in $1; do
+  i=$((i+1))
+  env "$kv" timeout -k 10 200 python3 bench.py --steps 6 --warmup 2 --no-cpu --check 2 > gpurun_out/ab_env_$i.json 2> gpurun_out/ab_env_$i.err || { echo "$kv failed"; tail -3 gpurun_out/ab_env_$i.err; exit 1; }
+  python3 -c "
+import json
+d=json.loads(open('gpurun_out/ab_env_$i.json').read().strip().splitlines()[-1]); print('$kv', d['ms_per_step'], d['parity_ok'])"
+done
