@@ -643,34 +643,57 @@ __global__ __launch_bounds__(256) void k_binmorph2d(Plane src, Plane dst, int w,
         }
         return make_uint4(d[0], d[1], d[2], d[3]);
     };
+    // looks at one row's pieces: picks up the image's value, and (CHECK) true when a byte is neither 0 nor the value
+    auto examine = [&](uint4& pa, uint4& pb) -> bool {
+        pa = bytes_of(pa, na);
+        pb = bytes_of(pb, nb);
+        const u32 any = pa.x | pa.y | pa.z | pa.w | pb.x | pb.y | pb.z | pb.w;
+        if (vmask == 0) {
+            const unsigned long long nz = __ballot(any != 0);
+            if (nz) {
+                u32 f = any | (any >> 16);
+                f = (f | (f >> 8)) & 0xffu;
+                vmask = (u32)__builtin_amdgcn_readlane((int)f, (int)__builtin_ctzll(nz)) * 0x01010101u;
+            }
+        }
+        if (!CHECK) return false;
+        // every byte must be 0 or the value: d == (0xff in its non-zero bytes) & vmask
+        u32 bad = 0;
+        const u32 dd[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const u32 nzb = pb_nonzero_bytes(dd[q]);
+            bad |= dd[q] ^ (((nzb << 8) - nzb) & vmask);
+        }
+        return __any(bad != 0);
+    };
+    if (CHECK) {
+        // Four rows spread over the strip first: an image with more than two values is usually found out here, before
+        // any of the real work (a thresholded plane pays four extra rows per strip).
+        uint4 qa[4], qb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int yy = min(r0 + (2 * k + 1) * strip_rows / 8, h - 1);
+            qa[k] = qb[k] = make_uint4(0, 0, 0, 0);
+            if (la) qa[k] = *(const uint4*)(sbase + (size_t)yy * src.pitch + xa);
+            if (lb) qb[k] = *(const uint4*)(sbase + (size_t)yy * src.pitch + xb);
+        }
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) found = found || examine(qa[k], qb[k]);
+        if (found) {
+            if (lane == 0) atomicOr(&flags[b], 1);
+            return;
+        }
+        if (__hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
     auto step = [&](int y, uint4 pa, uint4 pb) {  // y is the same in all lanes
         u32 in1 = 0xffffffffu;
         if (y >= 0 && y < h) {
-            pa = bytes_of(pa, na);
-            pb = bytes_of(pb, nb);
-            const u32 any = pa.x | pa.y | pa.z | pa.w | pb.x | pb.y | pb.z | pb.w;
-            if (vmask == 0) {
-                const unsigned long long nz = __ballot(any != 0);
-                if (nz) {
-                    u32 f = any | (any >> 16);
-                    f = (f | (f >> 8)) & 0xffu;
-                    vmask = (u32)__builtin_amdgcn_readlane((int)f, (int)__builtin_ctzll(nz)) * 0x01010101u;
-                }
-            }
-            if (CHECK) {
-                // every byte must be 0 or the value: d == (0xff in its non-zero bytes) & vmask
-                u32 bad = 0;
-                const u32 dd[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const u32 nzb = pb_nonzero_bytes(dd[q]);
-                    bad |= dd[q] ^ (((nzb << 8) - nzb) & vmask);
-                }
-                if (__any(bad != 0)) {
-                    if (lane == 0) atomicOr(&flags[b], 1);
-                    stop = true;
-                    return;
-                }
+            if (examine(pa, pb)) {
+                if (lane == 0) atomicOr(&flags[b], 1);
+                stop = true;
+                return;
             }
             const u32 hw = bm_pack16(pa) | (bm_pack16(pb) << 16);
             const u32 v0 = (u32)__shfl((int)hw, src_lane), v1 = (u32)__shfl((int)hw, src_lane + 1);
