@@ -130,8 +130,15 @@ __device__ __forceinline__ int hp_rho(int x, int y, float c, float s)
 //  * votes that trigger no segment commute, so the live pixels of a batch vote side by side
 //    (lane = pixel); if any bin they touched ends at or above the threshold the votes are taken
 //    back and the batch is replayed one visit at a time (lanes = angles / steps of the line walk).
-__global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
+__global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig Tk)
 {
+    // the tables are indexed per lane: from LDS, not from the kernel-argument segment (host memory)
+    __shared__ HpTrig T;
+    for (int n = threadIdx.x; n < HP_MAX_ANGLES; n += 64) {
+        T.c[n] = Tk.c[n];
+        T.s[n] = Tk.s[n];
+    }
+    __syncthreads();
     const int b = blockIdx.x, lane = threadIdx.x;
     int count = A.total[b];
     if (count < 0) {
@@ -400,6 +407,279 @@ __global__ __launch_bounds__(64) void k_hp_run(HpArgs A, HpTrig T)
     if (lane == 0) A.counts[b] = nlines;
 }
 
+// The same visits by a workgroup of NW waves per image.  Every wave runs the same (wave-uniform) control flow on the
+// same data, so all of them take the same decisions; what is bulk work inside a batch or a visit is split between
+// them: the angles of the speculative votes and of their maximum scan, the 64-step chunks of a line walk, the
+// pixels of a found segment that take their votes back.  The list of pixels is touched by wave 0 only.  Waves meet
+// at barriers that also wait for the memory operations issued before them.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_hp_run_mw(HpArgs A, HpTrig Tk)
+{
+    __shared__ HpTrig T;  // (indexed per lane: from LDS, not from the kernel-argument segment)
+    for (int n = threadIdx.x; n < HP_MAX_ANGLES; n += 64 * NW) {
+        T.c[n] = Tk.c[n];
+        T.s[n] = Tk.s[n];
+    }
+    __syncthreads();
+    __shared__ u32 s_p[64];
+    __shared__ u32 s_later[NW];
+    __shared__ int s_mx[NW][64];
+    __shared__ unsigned long long s_key[NW];
+    __shared__ unsigned long long s_M[2][NW], s_O[2][NW];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int count = A.total[b];
+    if (count < 0) {
+        if (threadIdx.x == 0) A.counts[b] = -1;
+        return;
+    }
+    u32* const bits = A.bits + (size_t)b * A.bsw;
+    u32* const nz = A.nz + (size_t)b * A.cap;
+    int32_t* const acc = A.accum + (size_t)b * A.accum_stride;
+    int32_t* const lines = A.lines + (size_t)b * A.max_lines * 4;
+    const int w = A.w, h = A.h, numangle = A.numangle, numrho = A.numrho, half = (numrho - 1) / 2;
+    const int shift = 16;
+    auto mask_at = [&](int i1, int j1) -> u32 { return (ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) >> (j1 & 31)) & 1u; };
+    // everything written before (memory, LDS) is seen by every wave behind it
+    auto sync = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    };
+    int nlines = 0;
+    int par = 0;  // which copy of s_M / s_O the next walk round writes
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tk = wall_clock64();
+    auto lap = [&](int q) { const long long now = wall_clock64(); st[q] += now - tk; tk = now; };
+
+    auto visit = [&](const int i, const int j) {
+        if (!mask_at(i, j)) return;  // already part of a segment
+        // vote; the winner is the first angle whose bin holds the largest count
+        int best_val = -1, best_n = 0;
+        for (int n = wv * 64 + lane; n < numangle; n += 64 * NW) {
+            const int val = atomicAdd(&acc[(size_t)n * numrho + hp_rho(j, i, T.c[n], T.s[n]) + half], 1) + 1;
+            if (val > best_val) {
+                best_val = val;
+                best_n = n;
+            }
+        }
+        unsigned long long key = ((unsigned long long)(u32)(best_val + 1) << 32) | (u32)(0x7fffffff - best_n);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other > key ? other : key;
+        }
+        if (lane == 0) s_key[wv] = key;
+        sync();
+        key = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) key = s_key[q] > key ? s_key[q] : key;
+        const int max_val = (int)(key >> 32) - 1, max_n = 0x7fffffff - (int)(u32)key;
+        lap(4);
+        if (max_val < A.threshold) return;
+
+        const float a = -T.s[max_n], bb = T.c[max_n];
+        int x0 = j, y0 = i, dx0, dy0;
+        bool xflag;
+        if (fabsf(a) > fabsf(bb)) {
+            xflag = true;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = __float2int_rn(__fdiv_rn(__fmul_rn(bb, 65536.0f), fabsf(a)));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = false;
+            dy0 = bb > 0 ? 1 : -1;
+            dx0 = __float2int_rn(__fdiv_rn(__fmul_rn(a, 65536.0f), fabsf(bb)));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        auto pos_at = [&](int k, int t, int& i1, int& j1) {
+            const int x = x0 + (k ? -dx0 : dx0) * t, y = y0 + (k ? -dy0 : dy0) * t;
+            j1 = xflag ? x : x >> shift;
+            i1 = xflag ? y >> shift : y;
+        };
+        // first walk: a round looks at 64 * NW steps, one chunk per wave; every wave then reads the chunks in order
+        int last_step[2] = {0, 0};
+        for (int k = 0; k < 2; k++) {
+            int gap = 0;
+            bool stop = false;
+            for (int base = 0; !stop; base += 64 * NW) {
+                {
+                    int i1, j1;
+                    pos_at(k, base + 64 * wv + lane, i1, j1);
+                    const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                    const u32 word = inb ? ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) : 0u;
+                    const unsigned long long M = __ballot(inb && ((word >> (j1 & 31)) & 1u)), O = __ballot(!inb);
+                    if (lane == 0) {
+                        s_M[par][wv] = M;
+                        s_O[par][wv] = O;
+                    }
+                }
+                sync();
+                for (int q = 0; q < NW && !stop; q++) {
+                    const unsigned long long M = s_M[par][q], O = s_O[par][q];
+                    if (O == 0 && M == ~0ULL) {
+                        gap = 0;
+                        last_step[k] = base + 64 * q + 63;
+                        continue;
+                    }
+                    for (int t = 0; t < 64; t++) {
+                        if ((O >> t) & 1ULL) {
+                            stop = true;
+                            break;
+                        }
+                        if ((M >> t) & 1ULL) {
+                            gap = 0;
+                            last_step[k] = base + 64 * q + t;
+                        } else if (++gap > A.line_gap) {
+                            stop = true;
+                            break;
+                        }
+                    }
+                }
+                par ^= 1;
+            }
+        }
+        lap(1);
+        int ex[2], ey[2];
+        pos_at(0, last_step[0], ey[0], ex[0]);
+        pos_at(1, last_step[1], ey[1], ex[1]);
+        const bool good = abs(ex[1] - ex[0]) >= A.line_length || abs(ey[1] - ey[0]) >= A.line_length;
+        // second walk: the segment's pixels leave the mask and, for a kept segment, take their votes back; a wave
+        // takes every NW-th chunk of 64 steps.  Step 0 belongs to both directions; it is handled once.
+        for (int k = 0; k < 2; k++) {
+            for (int base = k; base <= last_step[k]; base += 64 * NW) {
+                int i1, j1;
+                const int t = base + 64 * wv + lane;
+                pos_at(k, t, i1, j1);
+                const bool in_seg = t <= last_step[k];
+                u32* const wp = &bits[(size_t)i1 * A.bpw + (j1 >> 5)];
+                const u32 word = in_seg ? ld_l2(wp) : 0u;
+                const bool on = in_seg && ((word >> (j1 & 31)) & 1u);
+                unsigned long long m = __ballot(on);
+                if (on) atomicAnd(wp, ~(1u << (j1 & 31)));
+                if (good) {
+                    while (m) {
+                        const int tt = base + 64 * wv + (__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        int iu, ju;
+                        pos_at(k, tt, iu, ju);
+                        for (int n = lane; n < numangle; n += 64)
+                            atomicAdd(&acc[(size_t)n * numrho + hp_rho(ju, iu, T.c[n], T.s[n]) + half], -1);
+                    }
+                }
+            }
+        }
+        sync();  // the next visit reads what this one changed
+        lap(6);
+        if (good) {
+            if (threadIdx.x == 0 && nlines < A.max_lines) {
+                lines[4 * nlines + 0] = ex[0];
+                lines[4 * nlines + 1] = ey[0];
+                lines[4 * nlines + 2] = ex[1];
+                lines[4 * nlines + 3] = ey[1];
+            }
+            nlines++;
+        }
+    };
+
+    const unsigned long long RNG_COEFF = 4164903690ULL;
+    unsigned long long rng = 0xffffffffffffffffULL;
+    while (count > 0) {
+        st[5]++;
+        int K = count < 64 ? count : 64;
+        // the next K draws: lane t keeps the t-th (every wave computes the same)
+        unsigned long long x = rng;
+        u32 mine = 0;
+        for (int t = 0; t < K; t++) {
+            x = (unsigned long long)(u32)x * RNG_COEFF + (u32)(x >> 32);
+            if (lane == t) mine = (u32)x;
+        }
+        const u32 idx = lane < K ? mine % (u32)(count - lane) : 0xffffffffu;
+        u32 later = 64;
+        for (int u = 1 + wv; u < K; u += NW) {  // (this wave's share of the later partners)
+            const u32 iu = (u32)__builtin_amdgcn_readlane((int)idx, u);
+            if (lane < u && (idx == iu || idx == (u32)(count - 1 - u))) later = min(later, (u32)u);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) later = min(later, (u32)__shfl_xor((int)later, o));
+        if (lane == 0) s_later[wv] = later;
+        sync();
+#pragma unroll
+        for (int q = 0; q < NW; q++) later = min(later, s_later[q]);
+        if ((int)later < K) {
+            K = (int)later;
+            x = rng;
+            for (int t = 0; t < K; t++) x = (unsigned long long)(u32)x * RNG_COEFF + (u32)(x >> 32);
+        }
+        const bool act = lane < K;
+        lap(0);
+        // draw without replacement (wave 0): the last entry takes the drawn entry's place
+        if (wv == 0) {
+            u32 p0 = 0;
+            if (act) {
+                p0 = ld_l2(&nz[idx]);
+                const u32 last = ld_l2(&nz[count - 1 - lane]);
+                st_l2(&nz[idx], last);
+            }
+            s_p[lane] = p0;
+        }
+        sync();
+        const u32 p = s_p[lane];
+        const int pi = (int)(p >> 16), pj = (int)(p & 0xffffu);
+        lap(2);
+        // this wave's share of the angles; returns the largest count one of its votes produced
+        auto vote_all = [&](bool on, int delta) -> int {
+            int mx = 0;
+            if (on) {
+                for (int n0 = wv; n0 < numangle; n0 += 8 * NW) {  // eight atomics in flight per lane
+                    int v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int n = n0 + q * NW;
+                        v[q] = n < numangle ? atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], delta) + delta : 0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) mx = v[q] > mx ? v[q] : mx;
+                }
+            }
+            return mx;
+        };
+        auto unvote_all = [&](bool on) {
+            if (on)
+                for (int n = wv; n < numangle; n += NW)
+                    atomicAdd(&acc[(size_t)n * numrho + hp_rho(pj, pi, T.c[n], T.s[n]) + half], -1);
+        };
+        for (int start = 0; start < K;) {
+            const bool live = act && lane >= start && mask_at(pi, pj);
+            if (!__any(live)) break;
+            // The counts the votes return stand in for the final ones: the values one bin hands out are consecutive,
+            // so if the votes of the lanes up to t bring a bin to the threshold in cv2's order, at least one of THOSE
+            // lanes is handed a value at or above it, whatever the order the hardware serves them in: the first
+            // flagged lane is never behind the first lane that triggers.
+            int mx = vote_all(live, 1);
+            s_mx[wv][lane] = mx;
+            sync();
+#pragma unroll
+            for (int q = 0; q < NW; q++) mx = max(mx, s_mx[q][lane]);
+            const unsigned long long hot = __ballot(live && mx >= A.threshold);
+            lap(3);
+            if (!hot) break;
+            st[7]++;
+            const int t1 = __ffsll((long long)hot) - 1;
+            unvote_all(live && lane >= t1);
+            sync();
+            const u32 pt = (u32)__builtin_amdgcn_readlane((int)p, t1);
+            visit((int)(pt >> 16), (int)(pt & 0xffffu));
+            start = t1 + 1;
+            lap(4);
+        }
+        count -= K;
+        rng = x;
+    }
+    if (A.stats && b == 0 && threadIdx.x == 0)
+        for (int q = 0; q < 8; q++) A.stats[q] = st[q];
+    if (threadIdx.x == 0) A.counts[b] = nlines;
+}
+
 void hp_dims(int w, int h, double rho, double theta, int* numangle, int* numrho)
 {
     const float frho = (float)rho, ftheta = (float)theta;
@@ -505,7 +785,9 @@ IPA_EXPORT int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t
         if (!dbg) IPA_HIP(hipHostMalloc((void**)&dbg, 64, 0));
         A.stats = dbg;
         static long long* prev = nullptr;
-        if (prev) fprintf(stderr, "hp stats (10 ns ticks): rng+coll %lld seqfallback %lld list+mask %lld specvote %lld replay %lld | batches %lld collisions %lld replays %lld\n", prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], prev[7]);
+        // multi-wave kernel: [1] = first walks, [4] = votes of the visits, [6] = second walks (10 ns ticks);
+        // single-wave kernel: [1] unused, [4] = whole visits, [6] = batches cut short by a clash
+        if (prev) fprintf(stderr, "hp stats (10 ns ticks): draws %lld [1] %lld list %lld spec votes %lld [4] %lld | batches %lld [6] %lld replays %lld\n", prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], prev[7]);
         prev = dbg;
     }
     HpTrig T;
@@ -537,7 +819,17 @@ IPA_EXPORT int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t
         hipLaunchKernelGGL(k_hp_rowcount, rows, dim3(256), 0, st, B);
         hipLaunchKernelGGL(k_hp_scan, dim3((unsigned)nb), dim3(1024), 0, st, B);
         hipLaunchKernelGGL(k_hp_fill, rows, dim3(256), 0, st, B);
-        hipLaunchKernelGGL(k_hp_run, dim3((unsigned)nb), dim3(64), 0, st, B, T);
+        static int hp_waves = -1;  // IPA_HP_WAVES: waves per image (1 = the single-wave kernel, 16 = default)
+        if (hp_waves < 0) {
+            const char* e = getenv("IPA_HP_WAVES");
+            hp_waves = e ? atoi(e) : 16;
+        }
+        if (hp_waves >= 16)
+            hipLaunchKernelGGL(k_hp_run_mw<16>, dim3((unsigned)nb), dim3(1024), 0, st, B, T);
+        else if (hp_waves >= 4)
+            hipLaunchKernelGGL(k_hp_run_mw<4>, dim3((unsigned)nb), dim3(256), 0, st, B, T);
+        else
+            hipLaunchKernelGGL(k_hp_run, dim3((unsigned)nb), dim3(64), 0, st, B, T);
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;
