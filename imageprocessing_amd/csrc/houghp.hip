@@ -425,7 +425,8 @@ __global__ __launch_bounds__(64 * NW) void k_hp_run_mw(HpArgs A, HpTrig Tk)
     __shared__ u32 s_later[NW];
     __shared__ int s_mx[NW][64];
     __shared__ unsigned long long s_key[NW];
-    __shared__ unsigned long long s_M[2][NW], s_O[2][NW];
+    constexpr int WCH = 4;  // chunks of 64 walk steps per wave and round trip to the mask
+    __shared__ unsigned long long s_M[2][NW * WCH], s_O[2][NW * WCH];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int count = A.total[b];
@@ -496,42 +497,59 @@ __global__ __launch_bounds__(64 * NW) void k_hp_run_mw(HpArgs A, HpTrig Tk)
             j1 = xflag ? x : x >> shift;
             i1 = xflag ? y >> shift : y;
         };
-        // first walk: a round looks at 64 * NW steps, one chunk per wave; every wave then reads the chunks in order
+        // first walk, both directions at once: a round looks at 64 * WCH * NW / 2 steps of each (the first half of
+        // the waves one way, the second half the other, WCH chunks of 64 steps per wave); every wave then reads the
+        // chunks in order
+        constexpr int HW = NW / 2, CPR = HW * WCH;  // chunks per direction and round
         int last_step[2] = {0, 0};
-        for (int k = 0; k < 2; k++) {
-            int gap = 0;
-            bool stop = false;
-            for (int base = 0; !stop; base += 64 * NW) {
+        {
+            int gap[2] = {0, 0};
+            bool stop[2] = {false, false};
+            const int kd = wv >= HW ? 1 : 0, cq = wv - kd * HW;
+            for (int base = 0; !(stop[0] && stop[1]); base += 64 * CPR) {
                 {
-                    int i1, j1;
-                    pos_at(k, base + 64 * wv + lane, i1, j1);
-                    const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
-                    const u32 word = inb ? ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) : 0u;
-                    const unsigned long long M = __ballot(inb && ((word >> (j1 & 31)) & 1u)), O = __ballot(!inb);
-                    if (lane == 0) {
-                        s_M[par][wv] = M;
-                        s_O[par][wv] = O;
+                    u32 word[WCH];
+                    int bitpos[WCH];
+                    bool inb[WCH];
+#pragma unroll
+                    for (int m = 0; m < WCH; m++) {
+                        int i1, j1;
+                        pos_at(kd, base + 64 * (cq + HW * m) + lane, i1, j1);
+                        inb[m] = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                        bitpos[m] = j1 & 31;
+                        word[m] = inb[m] ? ld_l2(&bits[(size_t)i1 * A.bpw + (j1 >> 5)]) : 0u;
+                    }
+#pragma unroll
+                    for (int m = 0; m < WCH; m++) {
+                        const unsigned long long M = __ballot(inb[m] && ((word[m] >> bitpos[m]) & 1u)), O = __ballot(!inb[m]);
+                        if (lane == 0) {
+                            s_M[par][kd * CPR + cq + HW * m] = M;
+                            s_O[par][kd * CPR + cq + HW * m] = O;
+                        }
                     }
                 }
                 sync();
-                for (int q = 0; q < NW && !stop; q++) {
-                    const unsigned long long M = s_M[par][q], O = s_O[par][q];
-                    if (O == 0 && M == ~0ULL) {
-                        gap = 0;
-                        last_step[k] = base + 64 * q + 63;
-                        continue;
-                    }
-                    for (int t = 0; t < 64; t++) {
-                        if ((O >> t) & 1ULL) {
-                            stop = true;
-                            break;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    for (int q = 0; q < CPR && !stop[k2]; q++) {
+                        const unsigned long long M = s_M[par][k2 * CPR + q], O = s_O[par][k2 * CPR + q];
+                        if (O == 0 && M == ~0ULL) {
+                            gap[k2] = 0;
+                            last_step[k2] = base + 64 * q + 63;
+                            continue;
                         }
-                        if ((M >> t) & 1ULL) {
-                            gap = 0;
-                            last_step[k] = base + 64 * q + t;
-                        } else if (++gap > A.line_gap) {
-                            stop = true;
-                            break;
+                        for (int t = 0; t < 64; t++) {
+                            if ((O >> t) & 1ULL) {
+                                stop[k2] = true;
+                                break;
+                            }
+                            if ((M >> t) & 1ULL) {
+                                gap[k2] = 0;
+                                last_step[k2] = base + 64 * q + t;
+                            } else if (++gap[k2] > A.line_gap) {
+                                stop[k2] = true;
+                                break;
+                            }
                         }
                     }
                 }
