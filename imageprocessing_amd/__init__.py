@@ -2,7 +2,7 @@
 
 ``import imageprocessing_amd as cv2`` covers the calls the reference's diagram
 parsers make before their contour logic: cvtColor, threshold (binary / Otsu),
-adaptiveThreshold, GaussianBlur, getStructuringElement, erode, dilate,
+adaptiveThreshold, GaussianBlur, medianBlur, getStructuringElement, erode, dilate,
 morphologyEx, Canny, HoughLines, bitwise_or, bitwise_not.  The pixel work runs in
 hand-written HIP kernels (``libipamd_hip.so``, C ABI in ``include/ipamd.h``);
 PyTorch-ROCm only owns the device buffers.  There is no CPU implementation.

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ipa_front_end_chunks": (_i, [_i, _i, _i]),
     "ipa_front_end_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _i, _vp,
                               _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _sz, _vp]),
+    "ipa_median_blur_u8": (_i, [_vp, _sz, _sz, _vp, _sz, _sz, _i, _i, _i, _i, _vp]),
     "ipa_bits_pitch_words": (_sz, [_i]),
     "ipa_front_end_bits_u8": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _i, _vp,
                                    _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _sz, _vp, _vp, _vp]),

@@ -356,6 +356,93 @@ __global__ __launch_bounds__(256) void k_gauss_tile(Plane src, Plane dst, int w,
     }
 }
 
+// ---- median 3x3 / 5x5 -----------------------------------------------------------------------------
+// cv2.medianBlur(gray, 3 | 5).  One workgroup = 128 x 32 output pixels; the source tile with its halo (rows and
+// columns outside the image replaced by the nearest one inside) sits in LDS as bytes.  A lane takes two adjacent
+// pixels of a row: the K x K window values of both travel through the selection network side by side in the
+// halves of a dword (v_pk_min_u16 / v_pk_max_u16), K x K registers per lane.
+#include "median_nets.inc"
+constexpr int MED_TW = 128, MED_TR = 32;
+template <int K>
+struct MedNet;
+template <>
+struct MedNet<3> {
+    static constexpr int LEN = MED9_LEN, OUT = MED9_OUT;
+    static constexpr int net[MED9_LEN][2] = MED9_NET;
+};
+template <>
+struct MedNet<5> {
+    static constexpr int LEN = MED25_LEN, OUT = MED25_OUT;
+    static constexpr int net[MED25_LEN][2] = MED25_NET;
+};
+
+__device__ __forceinline__ u32 med_min(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(gt_us2, a), __builtin_bit_cast(gt_us2, b)));
+}
+__device__ __forceinline__ u32 med_max(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(gt_us2, a), __builtin_bit_cast(gt_us2, b)));
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_median(Plane src, Plane dst, int w, int h, int tiles_x, int tiles_y)
+{
+    constexpr int R = K / 2, ROWS = MED_TR + K - 1, PW = (MED_TW + K - 1 + 3) / 4 + 1;  // row pitch in dwords
+    __shared__ u32 tile[ROWS * PW];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int tx = blk % tiles_x;
+    blk /= tiles_x;
+    const int ty = blk % tiles_y, b = blk / tiles_y;
+    const int x0 = tx * MED_TW, y0 = ty * MED_TR;
+    // LDS column c <-> image column x0 - R + c, LDS row rr <-> image row y0 - R + rr (both clamped to the image)
+    for (int e = tid; e < ROWS * PW; e += 256) {
+        const int rr = e / PW, d = e - rr * PW;
+        const u8* row = src.row(b, min(max(y0 - R + rr, 0), h - 1));
+        const int gx = x0 - R + 4 * d;
+        u32 v;
+        if (gx >= 0 && gx + 4 <= w) {
+            v = *(const u32*)(row + gx);  // (any byte alignment)
+        } else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (u32)row[min(max(gx + j, 0), w - 1)] << (8 * j);
+        }
+        tile[e] = v;
+    }
+    __syncthreads();
+    const int wv = tid >> 6, lane = tid & 63;
+    const int x = x0 + 2 * lane;
+    const u32 off = (u32)(lane & 1) * 2u;  // byte of the lane's first column inside its first dword
+    for (int r = wv; r < MED_TR; r += 4) {
+        const int y = y0 + r;
+        if (y >= h) break;  // (uniform over the wave)
+        u32 p[K * K];
+#pragma unroll
+        for (int dy = 0; dy < K; dy++) {
+            const u32* tr = tile + (r + dy) * PW + (lane >> 1);
+            const u32 d0 = tr[0], d1 = tr[1], d2 = tr[2];
+            const u32 q0 = __builtin_amdgcn_alignbyte(d1, d0, off), q1 = __builtin_amdgcn_alignbyte(d2, d1, off);
+#pragma unroll
+            for (int c = 0; c < K; c++)  // low half: column c of the first pixel's window, high half: of the second's
+                p[dy * K + c] = __builtin_amdgcn_perm(q1, q0, 0x0c000c00u | (u32)c | ((u32)(c + 1) << 16));
+        }
+#pragma unroll
+        for (int c = 0; c < MedNet<K>::LEN; c++) {
+            constexpr auto& NET = MedNet<K>::net;
+            const int ia = NET[c][0], ib = NET[c][1];
+            const u32 lo = med_min(p[ia], p[ib]), hi = med_max(p[ia], p[ib]);
+            p[ia] = lo;
+            p[ib] = hi;
+        }
+        const u32 m = p[MedNet<K>::OUT];
+        u8* o = dst.row(b, y) + x;
+        if (x + 1 < w) *(unsigned short*)o = (unsigned short)((m & 0xffu) | ((m >> 16) << 8));
+        else if (x < w) *o = (u8)m;
+    }
+}
+
 // ---- adaptive threshold ----------------------------------------------------
 // row pass: float Gaussian (taps accumulated left to right) or integer box sums
 template <bool GAUSS>
@@ -899,6 +986,27 @@ IPA_EXPORT int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, s
         hipLaunchKernelGGL((k_adapt_col<false>), dim3(grid), dim3(256), 0, st, s, (const u32*)tmp, tp,
                            tp * (size_t)height, d, width, height, quads, total, T, box_scale, idelta, type, maxv);
     }
+    IPA_LAUNCH_CHECK();
+    return IPA_OK;
+}
+
+IPA_EXPORT int ipa_median_blur_u8(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
+                                  size_t dst_stride, int width, int height, int batch, int ksize, void* stream)
+{
+    IPA_REQUIRE(width >= 0 && height >= 0 && batch >= 0, IPA_ERR_ARG, "negative image size");
+    IPA_REQUIRE(ksize == 3 || ksize == 5, IPA_ERR_ARG, "medianBlur: ksize must be 3 or 5 (larger windows are not built)");
+    if (width == 0 || height == 0 || batch == 0) return IPA_OK;
+    Plane s = mkplane(src, src_pitch, src_stride), d = mkplane(dst, dst_pitch, dst_stride);
+    IPA_REQUIRE(plane_ok(s, (size_t)width, batch) && plane_ok(d, (size_t)width, batch), IPA_ERR_ALIGN,
+                "medianBlur: pointers/pitches must be 16-byte aligned and pitch >= row bytes");
+    IPA_REQUIRE(src != dst, IPA_ERR_ARG, "medianBlur: in place is not supported");
+    const int tiles_x = cdiv(width, MED_TW), tiles_y = cdiv(height, MED_TR);
+    const long long blocks = (long long)tiles_x * tiles_y * batch;
+    IPA_REQUIRE(blocks < 0x7fffffffLL, IPA_ERR_ARG, "medianBlur: too many tiles");
+    if (ksize == 3)
+        hipLaunchKernelGGL(k_median<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, d, width, height, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(k_median<5>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, d, width, height, tiles_x, tiles_y);
     IPA_LAUNCH_CHECK();
     return IPA_OK;
 }

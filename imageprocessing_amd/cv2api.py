@@ -167,6 +167,21 @@ def GaussianBlur(src, ksize, sigmaX, dst=None, sigmaY=0, borderType=BORDER_DEFAU
     return _ret(d, src)
 
 
+def medianBlur(src, ksize, dst=None):
+    """cv2.medianBlur on 8-bit single-channel images, ksize 3 or 5 ("New Version/textDetection.py":16,
+    "New Version/detectCircle.py":14, "New Version/detectShape.py":11)."""
+    L = _native.lib()
+    k = int(ksize)
+    if k % 2 != 1 or k <= 1:
+        raise error("medianBlur: ksize must be odd and greater than 1")
+    if k not in (3, 5):
+        raise error("medianBlur: only ksize 3 and 5 are supported")
+    s = upload(src, 1)
+    d = DevImage.empty(1, s.height, s.width, 1)
+    check(L.ipa_median_blur_u8(s.ptr, s.pitch, s.stride, d.ptr, d.pitch, d.stride, s.width, s.height, 1, k, stream_ptr()))
+    return _ret(d, src)
+
+
 # ---- morphology ------------------------------------------------------------------
 def getStructuringElement(shape, ksize, anchor=(-1, -1)):
     """cv2.getStructuringElement(MORPH_RECT, (cols, rows)) -> uint8[rows, cols] of ones

@@ -191,6 +191,15 @@ int ipa_gaussian_blur_u8(const uint8_t* src, size_t src_pitch, size_t src_stride
                          int kw, int kh, double sigma_x, double sigma_y, int border,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* cv2.medianBlur(gray, ksize) for ksize 3 and 5 on 8-bit single-channel images:
+ * "New Version/textDetection.py":16 (3, in front of the Otsu threshold of :23),
+ * "New Version/detectCircle.py":14, "New Version/detectShape.py":11 (5).
+ * Median of the ksize x ksize window, rows and columns outside the image replaced
+ * by the nearest one inside.  src and dst must differ.  No workspace. */
+int ipa_median_blur_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
+                       uint8_t* dst, size_t dst_pitch, size_t dst_stride,
+                       int width, int height, int batch, int ksize, void* stream);
+
 /* ---- morphology -------------------------------------------------------- */
 
 /* cv2.erode / cv2.dilate / cv2.morphologyEx(src, op, kernel, iterations) with an

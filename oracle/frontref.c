@@ -337,6 +337,47 @@ FR_API void fr_gaussian_kernel_q8(int n, double sigma, int* k)
     free(kd);
 }
 
+/* cv2.medianBlur(gray, ksize) on 8-bit single-channel images, ksize 3 or 5 --
+ * "New Version/textDetection.py":16 (3, feeding the Otsu threshold of :23),
+ * "New Version/detectCircle.py":14 and "New Version/detectShape.py":11 (5).
+ * OpenCV (modules/imgproc/src/median_blur.simd.hpp, medianBlur_SortNet) takes
+ * the median of the ksize x ksize window with the rows and columns outside the
+ * image replaced by the nearest one inside (BORDER_REPLICATE); a median is a
+ * value of the window, so every correct implementation gives the same bytes. */
+FR_API int fr_median_blur_u8(const u8* src, size_t sp, u8* dst, size_t dp, int w, int h, int ksize)
+{
+    if ((ksize != 3 && ksize != 5) || w < 0 || h < 0) return -1;
+    const int r = ksize / 2, n = ksize * ksize;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            u8 v[25];
+            int m = 0;
+            for (int dy = -r; dy <= r; dy++) {
+                int yy = y + dy;
+                yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+                for (int dx = -r; dx <= r; dx++) {
+                    int xx = x + dx;
+                    xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+                    v[m++] = src[(size_t)yy * sp + xx];
+                }
+            }
+            /* insertion sort of at most 25 values */
+            for (int i = 1; i < n; i++) {
+                u8 t = v[i];
+                int j = i - 1;
+                while (j >= 0 && v[j] > t) {
+                    v[j + 1] = v[j];
+                    j--;
+                }
+                v[j + 1] = t;
+            }
+            dst[(size_t)y * dp + x] = v[n / 2];
+        }
+    }
+    return 0;
+}
+
 /* cv2.GaussianBlur(gray, (kw,kh), sigmaX[, sigmaY, borderType]) on 8-bit
  * single-channel images -- NewVersion2/img2UML.py:26,
  * newVersion3/detect_arrow.py:16, newVersion3/detectHorizontalVerticalLines.py:58,

@@ -142,6 +142,17 @@ def gaussian_blur(gray, ksize, sigmaX, sigmaY=0.0, border=4):
     return out
 
 
+def median_blur(gray, ksize):
+    """cv2.medianBlur(gray, ksize) for ksize 3 or 5."""
+    gray = _c(gray)
+    h, w = gray.shape
+    out = np.empty((h, w), np.uint8)
+    rc = lib().fr_median_blur_u8(_p(gray), C.c_size_t(w), _p(out), C.c_size_t(w), w, h, int(ksize))
+    if rc != 0:
+        raise ValueError("bad medianBlur arguments")
+    return out
+
+
 def adaptive_threshold(gray, maxv, method, typ, block, Cc, return_mean=False):
     gray = _c(gray)
     h, w = gray.shape

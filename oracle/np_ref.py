@@ -118,6 +118,15 @@ def gaussian_blur_5x5_sigma0(gray: np.ndarray) -> np.ndarray:
     return ((acc + 128) >> 8).astype(np.uint8)
 
 
+def median_blur(gray: np.ndarray, ksize: int) -> np.ndarray:
+    """cv2.medianBlur(gray, ksize): median of the ksize x ksize window, BORDER_REPLICATE."""
+    r = ksize // 2
+    p = np.pad(gray, r, mode="edge")
+    h, w = gray.shape
+    stack = np.stack([p[dy : dy + h, dx : dx + w] for dy in range(ksize) for dx in range(ksize)])
+    return np.sort(stack, axis=0)[ksize * ksize // 2].astype(np.uint8)
+
+
 def gaussian_blur_3x3_sigma0(gray: np.ndarray) -> np.ndarray:
     k = np.array([1, 2, 1], dtype=np.int64)
     acc = ndimage.correlate(gray.astype(np.int64), np.outer(k, k), mode="mirror")

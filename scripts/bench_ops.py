@@ -89,6 +89,8 @@ def main():
         ("GaussianBlur 5x5 sigma 0", 2 * px, lambda: chk(L.ipa_gaussian_blur_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 5, 5, 0.0, 0.0, 4, ws.data_ptr(), ws.numel(), st))),
         ("GaussianBlur 5x5 sigma 1", 2 * px, lambda: chk(L.ipa_gaussian_blur_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 5, 5, 1.0, 0.0, 4, ws.data_ptr(), ws.numel(), st))),
         ("GaussianBlur 9x9 sigma 0", 2 * px, lambda: chk(L.ipa_gaussian_blur_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 9, 9, 0.0, 0.0, 4, ws.data_ptr(), ws.numel(), st))),
+        ("medianBlur 3", 2 * px, lambda: chk(L.ipa_median_blur_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 3, st))),
+        ("medianBlur 5", 2 * px, lambda: chk(L.ipa_median_blur_u8(gray.ptr, gray.pitch, gray.stride, out.ptr, out.pitch, out.stride, w, h, n, 5, st))),
         ("open 1x15 it=2 (binary)", 2 * px, morph(2, 1, 15, 2, 1, thr)),
         ("open 15x1 it=2 (binary)", 2 * px, morph(2, 15, 1, 2, 1, thr)),
         ("close 3x3 it=1 (binary)", 2 * px, morph(3, 3, 3, 1, 1, thr)),

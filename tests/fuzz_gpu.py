@@ -104,6 +104,9 @@ def ops_case(rng):
     ro, do = fr.threshold(g, t, mv, typ)
     if rt != ro or not np.array_equal(d, do):
         return f"threshold {w}x{h} {t} {mv} {typ}"
+    km = int(rng.choice([3, 5]))
+    if not np.array_equal(cv2.medianBlur(g, km), fr.median_blur(g, km)):
+        return f"medianBlur {w}x{h} {km}"
     for src in (g, binary):
         kw_, kh_ = int(rng.integers(1, 70)), int(rng.integers(1, 70))
         r = rng.random()

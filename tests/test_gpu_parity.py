@@ -189,6 +189,26 @@ def test_gaussian_streaming_kernel_shapes(h, w, ks, sx, border):
     assert np.array_equal(a, b), int((a != b).sum())
 
 
+@pytest.mark.parametrize("k", [3, 5])
+def test_median_blur(k):
+    # "New Version/textDetection.py":16 (3), "New Version/detectCircle.py":14 and detectShape.py:11 (5): random and smooth
+    # planes, sizes around the 128 x 32 tiles, single rows and columns, a torch tensor in, an unsupported size
+    import torch
+
+    for h, w in SIZES + [(1, 1), (1, 300), (300, 1), (2, 3), (32, 128), (33, 129), (31, 127), (64, 257), (70, 1000)]:
+        for g in (rand_gray(h * 3 + w + k, h, w), smooth_gray(h + w + k, h, w)):
+            a = cv2.medianBlur(g, k)
+            b = fr.median_blur(g, k)
+            assert a.dtype == np.uint8 and np.array_equal(a, b), (k, h, w, int((a != b).sum()))
+    t = torch.from_numpy(rand_gray(9, 80, 200)).cuda()
+    out = cv2.medianBlur(t, k)
+    assert isinstance(out, torch.Tensor) and np.array_equal(out.cpu().numpy(), fr.median_blur(t.cpu().numpy(), k))
+    with pytest.raises(cv2.error):
+        cv2.medianBlur(rand_gray(1, 10, 10), 7)
+    with pytest.raises(cv2.error):
+        cv2.medianBlur(rand_gray(1, 10, 10), 4)
+
+
 # ------------------------------------------------------------------ morphology
 MORPH_CASES = [((3, 3), 1), ((3, 3), 2), ((15, 1), 2), ((1, 15), 2), ((2, 2), 1), ((4, 3), 2), ((1, 1), 3), ((5, 7), 0),
                ((30, 1), 1), ((1, 30), 1), ((101, 1), 2), ((1, 101), 2), ((33, 1), 1), ((1, 64), 1)]

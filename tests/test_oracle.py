@@ -86,6 +86,29 @@ def test_gaussian_5x5_impulse():
     assert fr.gaussian_kernel_q8(5, 1.0).sum() == 256
 
 
+def test_median_blur_known_answers_and_c_vs_numpy():
+    # analytic: an isolated pixel vanishes, a 3-wide bar survives a 3x3 median except at its ends, the replicated
+    # border keeps a constant edge row; restatement: C vs numpy (scipy's median_filter with mode="nearest" as a third)
+    img = np.zeros((7, 9), np.uint8)
+    img[3, 4] = 200
+    assert fr.median_blur(img, 3).sum() == 0 and fr.median_blur(img, 5).sum() == 0
+    bar = np.zeros((7, 9), np.uint8)
+    bar[2:5, :] = 90
+    assert np.array_equal(fr.median_blur(bar, 3), bar)
+    edge = np.zeros((6, 6), np.uint8)
+    edge[0, :] = 255  # rows -1 (copy of row 0), 0 give 6 of 9 values
+    assert fr.median_blur(edge, 3)[0].tolist() == [255] * 6 and fr.median_blur(edge, 3)[1].sum() == 0
+    rng = np.random.default_rng(5)
+    for h, w in [(1, 1), (1, 17), (23, 1), (2, 2), (40, 53), (64, 128)]:
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for k in (3, 5):
+            a = fr.median_blur(g, k)
+            assert np.array_equal(a, nr.median_blur(g, k))
+            assert np.array_equal(a, ndimage.median_filter(g, size=k, mode="nearest"))
+    with pytest.raises(ValueError):
+        fr.median_blur(np.zeros((4, 4), np.uint8), 4)
+
+
 def test_canny_vertical_step():
     g = np.zeros((8, 12), np.uint8)
     g[:, 6:] = 255
