@@ -4,9 +4,10 @@
 //
 // The algorithm is sequential by construction: the non-zero pixels are visited in a pseudo-random
 // order (cv::RNG, multiply-with-carry), each visit reads and changes the accumulator and the pixel
-// mask, and a found segment removes its pixels before the next visit.  One WAVE therefore owns one
-// image and runs the visits in order; inside a visit the 64 lanes share the work (angles of a vote,
-// steps of a line walk), and a batch of images runs as many waves side by side.
+// mask, and a found segment removes its pixels before the next visit.  One WORKGROUP therefore owns one
+// image and runs the visits in order (k_hp_run_mw: its waves all run the same control flow and split the
+// bulk work; k_hp_run: the one-wave form); inside a wave the 64 lanes share the work (pixels of a batch of
+// draws, angles of a vote, steps of a line walk), and a batch of images runs as many workgroups side by side.
 //
 //   k_hp_rowcount / k_hp_scan / k_hp_fill   non-zero pixels as a list in raster order (the order
 //                                           the random draws index into) from the 1-bit plane
