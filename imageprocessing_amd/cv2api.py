@@ -26,6 +26,7 @@ COLOR_BGR2RGB = 4
 COLOR_RGB2BGR = 4
 COLOR_BGR2GRAY = 6
 COLOR_GRAY2BGR = 8
+COLOR_GRAY2RGB = 8  # (the same conversion: three copies of the gray value)
 THRESH_BINARY = 0
 THRESH_BINARY_INV = 1
 THRESH_OTSU = 8

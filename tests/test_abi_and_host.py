@@ -80,7 +80,7 @@ def test_cv2_names_and_constants():
                  "morphologyEx", "Canny", "HoughLines", "bitwise_or", "bitwise_not", "error", "front_end",
                  "front_end_batch", "edges_and_lines"):
         assert hasattr(cv2, name), name
-    assert (cv2.COLOR_BGR2GRAY, cv2.COLOR_GRAY2BGR, cv2.COLOR_BGR2RGB, cv2.COLOR_RGB2BGR) == (6, 8, 4, 4)
+    assert (cv2.COLOR_BGR2GRAY, cv2.COLOR_GRAY2BGR, cv2.COLOR_GRAY2RGB, cv2.COLOR_BGR2RGB, cv2.COLOR_RGB2BGR) == (6, 8, 8, 4, 4)
     assert (cv2.THRESH_BINARY, cv2.THRESH_BINARY_INV, cv2.THRESH_OTSU) == (0, 1, 8)
     assert (cv2.ADAPTIVE_THRESH_MEAN_C, cv2.ADAPTIVE_THRESH_GAUSSIAN_C) == (0, 1)
     assert (cv2.MORPH_RECT, cv2.MORPH_ERODE, cv2.MORPH_DILATE, cv2.MORPH_OPEN, cv2.MORPH_CLOSE) == (0, 0, 1, 2, 3)
