@@ -930,7 +930,19 @@ IPA_EXPORT int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, s
         const char* e = getenv("IPA_ADAPT_STREAM");
         astream = e ? atoi(e) : 1;
     }
-    const int R = block_size / 2;
+    int R = block_size / 2;
+    // Gaussian windows between the built sizes run in the next larger one with zero taps at both ends: a product
+    // with 0 is 0 and adding 0 changes no partial sum, so the float result is bit for bit the same.
+    if (astream && method == 1 && R < 15 && !(R == 1 || R == 2 || R == 3 || R == 5)) {
+        const int Rp = R < 5 ? 5 : 15;
+        TapsF P;
+        P.n = 2 * Rp + 1;
+        for (int i = 0; i < P.n; i++) P.f[i] = 0.f;
+        for (int i = 0; i < T.n; i++) P.f[i + (Rp - R)] = T.f[i];
+        T = P;
+        R = Rp;
+        block_size = 2 * Rp + 1;
+    }
     if (astream && (R == 1 || R == 2 || R == 3 || R == 5 || R == 15)) {
         // bands as tall as the launch allows (every band row-passes 2R + 4 rows before its first output row) while
         // the chip still gets two rounds of workgroups (four fit a CU)

@@ -145,10 +145,12 @@ def test_adaptive_threshold(block, method, typ):
 
 
 @pytest.mark.parametrize("h,w", [(1, 1), (3, 5), (64, 256), (65, 257), (130, 255), (200, 515), (9, 1027)])
-@pytest.mark.parametrize("block,method", [(11, 1), (31, 1), (7, 1), (11, 0), (31, 0), (5, 0), (9, 1), (13, 0)])
+@pytest.mark.parametrize("block,method", [(11, 1), (31, 1), (7, 1), (11, 0), (31, 0), (5, 0), (9, 1), (13, 0), (15, 1), (21, 1),
+                                          (29, 1), (33, 1)])
 def test_adaptive_threshold_shapes(h, w, block, method):
     # strip (256 columns) and band (64 / 128 rows) boundaries of the streaming kernel, images
-    # smaller than the window, and block sizes that take the two-pass kernels (9, 13)
+    # smaller than the window, Gaussian block sizes that run in the next larger built window with zero taps
+    # (9, 15, 21, 29) and sizes that take the two-pass kernels (box 13, Gaussian 33)
     g = rand_gray(h + 3 * w + block, h, w)
     for typ in (0, 1):
         a = cv2.adaptiveThreshold(g, 255, method, typ, block, 2)
