@@ -357,19 +357,14 @@ __global__ __launch_bounds__(256) void k_gauss_tile(Plane src, Plane dst, int w,
 }
 
 // ---- median 3x3 / 5x5 -----------------------------------------------------------------------------
-// cv2.medianBlur(gray, 3 | 5).  One workgroup = 128 x 32 output pixels; the source tile with its halo (rows and
-// columns outside the image replaced by the nearest one inside) sits in LDS as bytes.  A lane takes two adjacent
-// pixels of a row: the K x K window values of both travel through the selection network side by side in the
-// halves of a dword (v_pk_min_u16 / v_pk_max_u16), K x K registers per lane.
+// cv2.medianBlur(gray, 3 | 5).  The source tile with its halo (rows and columns outside the image replaced by the
+// nearest one inside) sits in LDS as bytes.  5 x 5 (k_median<5>): one workgroup = 128 x 32 output pixels, a lane takes
+// two adjacent pixels of a row: the 25 window values of both travel through the selection network side by side in
+// the halves of a dword (v_pk_min_u16 / v_pk_max_u16).  3 x 3: k_median3 below.
 #include "median_nets.inc"
 constexpr int MED_TW = 128, MED_TR = 32;
 template <int K>
 struct MedNet;
-template <>
-struct MedNet<3> {
-    static constexpr int LEN = MED9_LEN, OUT = MED9_OUT;
-    static constexpr int net[MED9_LEN][2] = MED9_NET;
-};
 template <>
 struct MedNet<5> {
     static constexpr int LEN = MED25_LEN, OUT = MED25_OUT;
@@ -383,6 +378,81 @@ __device__ __forceinline__ u32 med_min(u32 a, u32 b)
 __device__ __forceinline__ u32 med_max(u32 a, u32 b)
 {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(gt_us2, a), __builtin_bit_cast(gt_us2, b)));
+}
+
+// 3 x 3: a lane takes 4 adjacent columns of 2 adjacent rows.  The two rows travel in the halves of a dword (window
+// rows y-1..y+1 in the low half, y..y+2 in the high half), every column of three is sorted once and serves the three
+// windows it belongs to: median = med3(max of the columns' smallest, med3 of their middle ones, min of their largest).
+// About 15 packed operations per pixel instead of 30, aligned LDS reads, one dword store per lane and row.
+constexpr int M3_TW = 256, M3_TR = 32;
+__device__ __forceinline__ u32 med3(u32 a, u32 b, u32 c) { return med_max(med_min(a, b), med_min(med_max(a, b), c)); }
+
+__global__ __launch_bounds__(256) void k_median3(Plane src, Plane dst, int w, int h, int tiles_x, int tiles_y)
+{
+    constexpr int ROWS = M3_TR + 2, PW = M3_TW / 4 + 2;  // LDS column c <-> image column x0 - 1 + c; 66 dwords per row
+    __shared__ u32 tile[ROWS * PW];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int tx = blk % tiles_x;
+    blk /= tiles_x;
+    const int ty = blk % tiles_y, b = blk / tiles_y;
+    const int x0 = tx * M3_TW, y0 = ty * M3_TR;
+    for (int e = tid; e < ROWS * PW; e += 256) {
+        const int rr = e / PW, d = e - rr * PW;
+        const u8* row = src.row(b, min(max(y0 - 1 + rr, 0), h - 1));
+        const int gx = x0 - 1 + 4 * d;
+        u32 v;
+        if (gx >= 0 && gx + 4 <= w) {
+            v = *(const u32*)(row + gx);  // (any byte alignment)
+        } else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (u32)row[min(max(gx + j, 0), w - 1)] << (8 * j);
+        }
+        tile[e] = v;
+    }
+    __syncthreads();
+    const int wv = tid >> 6, lane = tid & 63;
+    const int x = x0 + 4 * lane;
+    for (int rp = wv; rp < M3_TR / 2; rp += 4) {
+        const int y = y0 + 2 * rp;
+        if (y >= h) break;  // (uniform over the wave)
+        // rows y-1 .. y+2 of the tile, columns x-1 .. x+6 (two dwords each)
+        u32 ra[4], rb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const u32* tr = tile + (2 * rp + i) * PW + lane;
+            ra[i] = tr[0];
+            rb[i] = tr[1];
+        }
+        u32 lo[6], mid[6], hi[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            // byte j of row i in the low half, of row i + 1 in the high half
+            u32 e[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const u32 r0 = j < 4 ? ra[i] : rb[i], r1 = j < 4 ? ra[i + 1] : rb[i + 1];
+                e[i] = __builtin_amdgcn_perm(r1, r0, 0x0c000c00u | (u32)(j & 3) | ((u32)(4 + (j & 3)) << 16));
+            }
+            const u32 a = med_min(e[0], e[1]), bq = med_max(e[0], e[1]);
+            lo[j] = med_min(a, e[2]);
+            const u32 t = med_max(a, e[2]);
+            mid[j] = med_min(bq, t);
+            hi[j] = med_max(bq, t);
+        }
+        u32 m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            m[k] = med3(med_max(med_max(lo[k], lo[k + 1]), lo[k + 2]), med3(mid[k], mid[k + 1], mid[k + 2]),
+                        med_min(med_min(hi[k], hi[k + 1]), hi[k + 2]));
+        if (x < w) {  // (bytes past the width stay inside the pitch)
+            const u32 o0 = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0400u) | __builtin_amdgcn_perm(m[3], m[2], 0x04000c0cu);
+            const u32 o1 = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0602u) | __builtin_amdgcn_perm(m[3], m[2], 0x06020c0cu);
+            *(u32*)(dst.row(b, y) + x) = o0;
+            if (y + 1 < h) *(u32*)(dst.row(b, y + 1) + x) = o1;
+        }
+    }
 }
 
 template <int K>
@@ -1015,9 +1085,11 @@ IPA_EXPORT int ipa_median_blur_u8(const uint8_t* src, size_t src_pitch, size_t s
     const int tiles_x = cdiv(width, MED_TW), tiles_y = cdiv(height, MED_TR);
     const long long blocks = (long long)tiles_x * tiles_y * batch;
     IPA_REQUIRE(blocks < 0x7fffffffLL, IPA_ERR_ARG, "medianBlur: too many tiles");
-    if (ksize == 3)
-        hipLaunchKernelGGL(k_median<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, d, width, height, tiles_x, tiles_y);
-    else
+    if (ksize == 3) {
+        const int tx3 = cdiv(width, M3_TW), ty3 = cdiv(height, M3_TR);
+        const long long blocks3 = (long long)tx3 * ty3 * batch;
+        hipLaunchKernelGGL(k_median3, dim3((unsigned)blocks3), dim3(256), 0, (hipStream_t)stream, s, d, width, height, tx3, ty3);
+    } else
         hipLaunchKernelGGL(k_median<5>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, d, width, height, tiles_x, tiles_y);
     IPA_LAUNCH_CHECK();
     return IPA_OK;
