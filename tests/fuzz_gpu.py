@@ -317,6 +317,24 @@ def abi_case(rng):
                           ws.data_ptr(), ws.numel(), sp), "morph")
         if not np.array_equal(D.get(), np.stack([fr.morphology_ex(arr[b], op, (kw_, kh_), it) for b in range(n)])):
             return f"ipa_morph_u8 n={n} {w}x{h} op={op} k=({kw_},{kh_}) it={it} binary={binary} pitches {src.pitch}/{D.pitch}"
+    # two-valued and gray images in one batch, content not promised (the one-pass two-valued kernel gives up per image)
+    if n >= 2:
+        mixed = np.where((np.arange(n) % 2 == 0)[:, None, None], th, gray)
+        MX = Dev(rng, n, h, w, mixed)
+        kw_, kh_ = int(rng.integers(1, 34)), int(rng.integers(1, 20))
+        it, op = int(rng.integers(1, 3)), int(rng.integers(0, 4))
+        ws = ws_for(L.ipa_morph_workspace_bytes(w, h, n))
+        D = Dev(rng, n, h, w)
+        ok(L.ipa_morph_u8(MX.ptr, MX.pitch, MX.stride, D.ptr, D.pitch, D.stride, w, h, n, op, kw_, kh_, -1, -1, it, 0,
+                          ws.data_ptr(), ws.numel(), sp), "morph mixed")
+        if not np.array_equal(D.get(), np.stack([fr.morphology_ex(mixed[b], op, (kw_, kh_), it) for b in range(n)])):
+            return f"ipa_morph_u8 mixed batch n={n} {w}x{h} op={op} k=({kw_},{kh_}) it={it}"
+    # medianBlur
+    km = int(rng.choice([3, 5]))
+    D = Dev(rng, n, h, w)
+    ok(L.ipa_median_blur_u8(G.ptr, G.pitch, G.stride, D.ptr, D.pitch, D.stride, w, h, n, km, sp), "median")
+    if not np.array_equal(D.get(), np.stack([fr.median_blur(gray[b], km) for b in range(n)])):
+        return f"ipa_median_blur_u8 n={n} {w}x{h} {km}"
     # GaussianBlur
     kx, ky = 2 * int(rng.integers(0, 6)) + 1, 2 * int(rng.integers(0, 6)) + 1
     ws = ws_for(L.ipa_gaussian_blur_workspace_bytes(w, h, n))
@@ -371,9 +389,15 @@ def abi_case(rng):
     tv = int(rng.integers(0, 256))
     ws = ws_for(L.ipa_front_end_workspace_bytes(w, h, n, 0 if hough else 1))
     acc.fill_(-7)
-    ok(L.ipa_front_end_u8(S.ptr, S.pitch, S.stride, P[0].ptr, P[1].ptr, P[2].ptr, P[3].ptr, P[4].ptr, P[0].pitch, P[0].stride,
-                          acc.data_ptr() if hough else None, astride, None, 0 if hough else 1, cnt.data_ptr(), w, h, n, tv, 15, 15, 2,
-                          lo, hi, 0, ws.data_ptr(), ws.numel(), sp), "front_end")
+    bpw = int(L.ipa_bits_pitch_words(w))
+    line_bits = torch.full((2, n, h, bpw), -1, dtype=torch.int32, device="cuda") if rng.random() < 0.5 else None
+    fe_args = (S.ptr, S.pitch, S.stride, P[0].ptr, P[1].ptr, P[2].ptr, P[3].ptr, P[4].ptr, P[0].pitch, P[0].stride,
+               acc.data_ptr() if hough else None, astride, None, 0 if hough else 1, cnt.data_ptr(), w, h, n, tv, 15, 15, 2,
+               lo, hi, 0, ws.data_ptr(), ws.numel(), sp)
+    if line_bits is None:
+        ok(L.ipa_front_end_u8(*fe_args), "front_end")
+    else:
+        ok(L.ipa_front_end_bits_u8(*fe_args, line_bits[0].data_ptr(), line_bits[1].data_ptr()), "front_end_bits")
     a = acc.cpu().numpy()
     for b in sorted(set([0, n - 1])):
         exp = oracle_case(bgr[b], tv, 15, 15, 2, lo, hi, False, hough, True)
@@ -382,6 +406,18 @@ def abi_case(rng):
                 return f"ipa_front_end_u8 n={n} {w}x{h} image {b} plane {name} pitch {P[0].pitch} stride {P[0].stride}"
         if hough and not np.array_equal(a[b * astride : b * astride + cells].reshape(na + 2, nr + 2), exp[5]):
             return f"ipa_front_end_u8 n={n} {w}x{h} image {b} accum"
+    if line_bits is not None:  # the segment pass straight from the bit planes of the two opens
+        cnt2 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for which, k in ((0, 2), (1, 3)):
+            ws2 = ws_for(L.ipa_segments_workspace_bytes(w, h, n, w * h))
+            ok(L.ipa_segments_bits_u32(line_bits[which].data_ptr(), bpw, bpw * h, w, h, n, w * h, boxes.data_ptr(), 4096, cnt2.data_ptr(),
+                                       ws2.data_ptr(), ws2.numel(), sp), "segments_bits")
+            c2, bx2 = cnt2.cpu().numpy(), boxes.cpu().numpy()
+            masks = P[k].get()
+            for b in range(n):
+                exp2 = fr.external_boxes(masks[b])
+                if c2[b] != len(exp2) or (c2[b] <= 4096 and not np.array_equal(bx2[b, : c2[b]], exp2)):
+                    return f"ipa_segments_bits_u32 n={n} {w}x{h} plane {k} image {b}"
     # nothing outside the images' rows may change except row tails up to the pitch
     for d in (G, E, P[0]):
         flat = d.t.cpu().numpy()
