@@ -220,6 +220,10 @@ struct GaussTileTaps {
     u32 y2o[GT_G2];      // taps (2j-1, 2j)
 };
 
+// NG4 / NPM: compile-time copies of the number of four-tap groups along a row and of the tap pairs down a column for
+// the common square sizes (0 = run-time loops): the loops then have no exits, so all LDS reads of an item are issued
+// before the first is used.
+template <int NG4, int NPM>
 __global__ __launch_bounds__(256) void k_gauss_tile(Plane src, Plane dst, int w, int h, int tiles_x, int tiles_y, GaussTileTaps T)
 {
     extern __shared__ __align__(16) u8 gt_smem[];
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(256) void k_gauss_tile(Plane src, Plane dst, int w,
             u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             u32 cur = rowp[0];
 #pragma unroll
-            for (int j = 0; j < GT_G4; j++) {
-                if (j >= ng4) break;  // (wave-uniform)
+            for (int j = 0; j < (NG4 ? NG4 : GT_G4); j++) {
+                if (!NG4 && j >= ng4) break;  // (wave-uniform)
                 const u32 nxt = rowp[j + 1];
                 const u32 k = T.x4[j];
                 a0 = __builtin_amdgcn_udot4(cur, k, a0, false);
@@ -343,8 +347,8 @@ __global__ __launch_bounds__(256) void k_gauss_tile(Plane src, Plane dst, int w,
         const u32* col = hz + (size_t)(r >> 1) * GT_W + 4 * c4;
         u32 a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
 #pragma unroll
-        for (int j = 0; j < GT_G2; j++) {
-            if (j >= np) break;
+        for (int j = 0; j < (NPM ? NPM : GT_G2); j++) {
+            if (!NPM && j >= np) break;  // (NPM: taps beyond the window are zero, the rows read for them exist)
             const uint4 v = *(const uint4*)(col + (size_t)j * GT_W);
             const gt_us2 k = __builtin_bit_cast(gt_us2, odd ? T.y2o[j] : T.y2e[j]);
             a0 = __builtin_amdgcn_udot2(__builtin_bit_cast(gt_us2, v.x), k, a0, false);
@@ -912,10 +916,18 @@ static int gaussian_impl(Plane s, Plane d, int width, int height, int batch, int
         const size_t lds = (size_t)SR * SPW * 4 + (size_t)(SR / 2) * GT_W * 4;
         static bool attr_set = false;
         if (lds > 48 * 1024 && !attr_set) {
-            IPA_HIP(hipFuncSetAttribute((const void*)k_gauss_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            IPA_HIP(hipFuncSetAttribute((const void*)k_gauss_tile<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_gauss_tile, dim3((unsigned)blocks), dim3(256), lds, st, s, d, width, height, tiles_x, tiles_y, T);
+#define IPA_GT(G4, PM) hipLaunchKernelGGL((k_gauss_tile<G4, PM>), dim3((unsigned)blocks), dim3(256), lds, st, s, d, width, height, tiles_x, tiles_y, T)
+        // the common square windows (their LDS need stays below 48 KiB) with unrolled tap loops
+        if (kw == 7 && kh == 7) IPA_GT(2, 4);
+        else if (kw == 9 && kh == 9) IPA_GT(3, 5);
+        else if (kw == 11 && kh == 11) IPA_GT(3, 6);
+        else if (kw == 13 && kh == 13) IPA_GT(4, 7);
+        else if (kw == 15 && kh == 15) IPA_GT(4, 8);
+        else IPA_GT(0, 0);
+#undef IPA_GT
         IPA_LAUNCH_CHECK();
         return IPA_OK;
     }
