@@ -1203,64 +1203,60 @@ __global__ __launch_bounds__(64) void k_morph_col_vhgw(Plane src, Plane dst, int
     // first block: the one that holds row Y0 - a (floor division for negative rows)
     const int lo0 = Y0 - a;
     int r = (lo0 >= 0 ? lo0 / k : -((-lo0 + k - 1) / k)) * k;
-    const u8* const sbase = src.p + (size_t)b * src.stride + (size_t)dx * 4;
+    // Every lane loads every row (from the nearest dword and row inside the image; what lies outside is replaced by
+    // the identity when the row is consumed): with loads that may or may not be issued the compiler cannot count
+    // how many younger ones may stay in flight, and waits for all of them.
+    const u8* const sbase = src.p + (size_t)b * src.stride + (size_t)min(dx, dwords - 1) * 4;
     u8* const dbase = dst.p + (size_t)b * dst.stride + (size_t)dx * 4;
-    auto load_row = [&](int yy) -> u32 {
-        u32 v = ident;
-        if (live && yy >= 0 && yy < h) v = *(const u32*)(sbase + (size_t)yy * src.pitch);
-        return v;
-    };
-    constexpr int PF = 8;  // rows in flight ahead of the row being consumed
-    u32 q[PF];
+    auto load_row = [&](int yy) -> u32 { return *(const u32*)(sbase + (size_t)min(max(yy, 0), h - 1) * src.pitch); };
+    // Rows are taken sixteen at a time whatever the block length is, from two sets of eight registers: while one set
+    // is consumed the other is loaded (eight rows ahead).  No value moves to another register while its load is
+    // under way - a move makes the wave wait for every load it has issued.  The end of a block is a wave-uniform
+    // branch behind any of the rows.
+    constexpr int PF = 8;
+    u32 qa[PF], qb[PF];
 #pragma unroll
-    for (int j = 0; j < PF; j++) q[j] = load_row(r + j);
-    int ahead = r + PF;  // next row to request
+    for (int j = 0; j < PF; j++) qa[j] = load_row(r + j);
+    const int y_last = Y1 + k - 2 - a;  // last source row of the band's last window
     bool have_prev = false;
-    for (; r - (k - 1) + a < Y1; r += k) {  // the block's first output row is r - (k-1) + a
-        u32 pre = ident;
-        for (int i0 = 0; i0 < k; i0 += PF) {
-#pragma unroll
-            for (int j = 0; j < PF; j++) {
-                const int i = i0 + j;
-                if (i < k) {  // (wave-uniform)
-                    const u32 v = q[j];
-                    q[j] = load_row(ahead++);
-                    const int yy = r + i;
-                    bytes_minmax_acc<DIL>(pre, v);
-                    // the window that ends at row yy: output row yo; its first row is row i + 1 of the previous block
-                    const int yo = yy - (k - 1) + a;
-                    u32 out = pre;
-                    if (i < k - 1) {
-                        const u32 sprev = have_prev ? ring[(i + 1) * 64 + lane] : ident;
-                        bytes_minmax_acc<DIL>(out, sprev);
-                    }
-                    ring[i * 64 + lane] = v;
-                    if (live && yo >= Y0 && yo < Y1 && (have_prev || i == k - 1)) *(u32*)(dbase + (size_t)yo * dst.pitch) = out;
-                }
-            }
-            // a block that ends inside a group of PF: the rows already requested belong to the next block
-            if (i0 + PF > k) {
-                const int used = k - i0;  // 1 .. PF-1 rows of this group were consumed: move the rest to the front
-                u32 t[PF];
-#pragma unroll
-                for (int j = 0; j < PF; j++) t[j] = q[j];
-#pragma unroll
-                for (int j = 0; j < PF; j++) {
-                    u32 v = t[j];
-#pragma unroll
-                    for (int u = 1; u < PF; u++)
-                        if (used == u) v = t[(j + u) % PF];
-                    q[j] = v;
-                }
-            }
+    int i = 0;  // position of the next row inside its block
+    u32 pre = ident;
+    auto row = [&](const u32 loaded, const int y) {
+        const u32 v = y >= 0 && y < h ? loaded : ident;
+        bytes_minmax_acc<DIL>(pre, v);
+        // the window that ends at row y: output row yo; its first row is row i + 1 of the previous block
+        const int yo = y - (k - 1) + a;
+        u32 out = pre;
+        if (i < k - 1) {
+            const u32 sprev = have_prev ? ring[(i + 1) * 64 + lane] : ident;
+            bytes_minmax_acc<DIL>(out, sprev);
         }
-        // suffix minima of the block, in place
-        u32 suf = ring[(k - 1) * 64 + lane];
-        for (int i = k - 2; i >= 0; i--) {
-            bytes_minmax_acc<DIL>(suf, ring[i * 64 + lane]);
-            ring[i * 64 + lane] = suf;
+        ring[i * 64 + lane] = v;
+        // (rows past y_last in the last group write nothing: their output rows lie below the band)
+        if (live && yo >= Y0 && yo < Y1 && (have_prev || i == k - 1)) *(u32*)(dbase + (size_t)yo * dst.pitch) = out;
+        if (++i == k) {
+            // suffix minima of the block, in place
+            u32 suf = ring[(k - 1) * 64 + lane];
+            for (int e = k - 2; e >= 0; e--) {
+                bytes_minmax_acc<DIL>(suf, ring[e * 64 + lane]);
+                ring[e * 64 + lane] = suf;
+            }
+            have_prev = true;
+            i = 0;
+            pre = ident;
         }
-        have_prev = true;
+    };
+    for (int yy = r; yy <= y_last; yy += 2 * PF) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            row(qa[j], yy + j);
+            qb[j] = load_row(yy + PF + j);
+        }
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            row(qb[j], yy + PF + j);
+            qa[j] = load_row(yy + 2 * PF + j);
+        }
     }
 }
 
@@ -1533,7 +1529,12 @@ int launch_morph_generic(Plane src, Plane dst, Plane tmp, int w, int h, int batc
             // the rows a band reads above its first output stay a small part) give the launch its parallelism
             const int strips = cdiv(dwords, 64);
             int band_rows = h;
-            while (band_rows / 2 >= 4 * ky && (long long)strips * cdiv(h, band_rows) * batch < 4096) band_rows = (band_rows + 1) / 2;
+            static int vhgw_blocks = -1;  // IPA_VHGW_BLOCKS: workgroups a launch should reach before bands stop shrinking
+            if (vhgw_blocks < 0) {
+                const char* e = getenv("IPA_VHGW_BLOCKS");
+                vhgw_blocks = e ? atoi(e) : 4096;
+            }
+            while (band_rows / 2 >= 4 * ky && (long long)strips * cdiv(h, band_rows) * batch < vhgw_blocks) band_rows = (band_rows + 1) / 2;
             const int bands = cdiv(h, band_rows);
             const long long blocks = (long long)strips * bands * batch;
             if (blocks > 0x7fffffffLL) {
