@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void k_adapt_col(Plane src, const u32* __restr
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 template <int R, bool GAUSS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_adapt_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R > 5 ? 4 : 6, R > 5 ? 4 : 8))) void k_adapt_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
                                                       int band_rows, TapsF T, double box_scale, int idelta, int inv,
                                                       u32 maxv)
 {
@@ -1032,7 +1032,13 @@ IPA_EXPORT int ipa_adaptive_threshold_u8(const uint8_t* src, size_t src_pitch, s
         const int min_rows = R <= 5 ? 64 : 128;
         const long long per_band = (long long)strips_x * batch;
         const int max_bands = cdiv(height, min_rows);
-        const int bands0 = (int)std::max<long long>(1, std::min<long long>(max_bands, (2LL * 4 * 256 + per_band - 1) / per_band));
+        static int adapt_rounds = -1;  // IPA_ADAPT_ROUNDS: rounds of workgroups a launch should reach
+        if (adapt_rounds < 0) {
+            const char* e = getenv("IPA_ADAPT_ROUNDS");
+            adapt_rounds = e ? atoi(e) : 4;
+        }
+        const int fit = R <= 5 ? 8 : 4;  // workgroups per CU
+        const int bands0 = (int)std::max<long long>(1, std::min<long long>(max_bands, ((long long)adapt_rounds * fit * 256 + per_band - 1) / per_band));
         const int band_rows = (cdiv(height, bands0) + 3) & ~3;
         const int bands = cdiv(height, band_rows);
         const long long nwgs = per_band * bands;
