@@ -401,19 +401,33 @@ __global__ __launch_bounds__(256) void k_median3(Plane src, Plane dst, int w, in
     blk /= tiles_x;
     const int ty = blk % tiles_y, b = blk / tiles_y;
     const int x0 = tx * M3_TW, y0 = ty * M3_TR;
-    for (int e = tid; e < ROWS * PW; e += 256) {
-        const int rr = e / PW, d = e - rr * PW;
-        const u8* row = src.row(b, min(max(y0 - 1 + rr, 0), h - 1));
-        const int gx = x0 - 1 + 4 * d;
-        u32 v;
-        if (gx >= 0 && gx + 4 <= w) {
-            v = *(const u32*)(row + gx);  // (any byte alignment)
-        } else {
-            v = 0;
+    if (x0 - 1 >= 0 && x0 - 1 + 4 * PW <= w) {  // (uniform) no column outside the image: every load is issued before the first is used
+        constexpr int PER = (ROWS * PW + 255) / 256;
+        u32 v[PER];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v |= (u32)row[min(max(gx + j, 0), w - 1)] << (8 * j);
+        for (int q = 0; q < PER; q++) {
+            const int e = min(tid + 256 * q, ROWS * PW - 1);
+            const int rr = e / PW, d = e - rr * PW;
+            v[q] = *(const u32*)(src.row(b, min(max(y0 - 1 + rr, 0), h - 1)) + x0 - 1 + 4 * d);  // (any byte alignment)
         }
-        tile[e] = v;
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (tid + 256 * q < ROWS * PW) tile[tid + 256 * q] = v[q];
+    } else {
+        for (int e = tid; e < ROWS * PW; e += 256) {
+            const int rr = e / PW, d = e - rr * PW;
+            const u8* row = src.row(b, min(max(y0 - 1 + rr, 0), h - 1));
+            const int gx = x0 - 1 + 4 * d;
+            u32 v;
+            if (gx >= 0 && gx + 4 <= w) {
+                v = *(const u32*)(row + gx);  // (any byte alignment)
+            } else {
+                v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v |= (u32)row[min(max(gx + j, 0), w - 1)] << (8 * j);
+            }
+            tile[e] = v;
+        }
     }
     __syncthreads();
     const int wv = tid >> 6, lane = tid & 63;
