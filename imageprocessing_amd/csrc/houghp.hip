@@ -575,14 +575,32 @@ __global__ __launch_bounds__(64 * NW) void k_hp_run_mw(HpArgs A, HpTrig Tk)
                 const bool on = in_seg && ((word >> (j1 & 31)) & 1u);
                 unsigned long long m = __ballot(on);
                 if (on) atomicAnd(wp, ~(1u << (j1 & 31)));
-                if (good) {
-                    while (m) {
-                        const int tt = base + 64 * wv + (__ffsll((long long)m) - 1);
-                        m &= m - 1;
-                        int iu, ju;
-                        pos_at(k, tt, iu, ju);
-                        for (int n = lane; n < numangle; n += 64)
-                            atomicAdd(&acc[(size_t)n * numrho + hp_rho(ju, iu, T.c[n], T.s[n]) + half], -1);
+                if (good && m) {
+                    // Lane = angle, the chunk's pixels one after the other: neighbouring pixels of a segment fall into
+                    // the same bin of the angles near its normal, and a lane takes such a run back with one atomic
+                    // (lane = pixel sends the pixels of all waves to the same few addresses in L2, where they queue
+                    // up).  Bins may go below zero, as in cv2: pixels that have not voted yet leave as well.
+                    for (int g = 0; g < numangle; g += 64) {
+                        const int n = g + lane;
+                        const bool av = n < numangle;
+                        const float cn = av ? T.c[n] : 0.f, sn = av ? T.s[n] : 0.f;
+                        int32_t* const rowp = acc + (size_t)(av ? n : 0) * numrho + half;
+                        int cur = 0, cnt = 0;
+                        unsigned long long mm = m;
+                        while (mm) {
+                            const int tt = base + 64 * wv + (__ffsll((long long)mm) - 1);
+                            mm &= mm - 1;
+                            int iu, ju;
+                            pos_at(k, tt, iu, ju);
+                            const int rr = hp_rho(ju, iu, cn, sn);
+                            if (av && cnt != 0 && rr != cur) {
+                                atomicAdd(&rowp[cur], -cnt);
+                                cnt = 0;
+                            }
+                            cur = rr;
+                            cnt++;
+                        }
+                        if (av) atomicAdd(&rowp[cur], -cnt);
                     }
                 }
             }
