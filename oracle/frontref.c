@@ -587,13 +587,14 @@ FR_API void fr_canny(const u8* src, size_t sp, u8* dst, size_t dp, int w, int h,
 #undef MAG
     if (map_out) memcpy(map_out, map, n);
     /* hysteresis: flood from every strong pixel through weak candidates */
-    int* stack = (int*)malloc(sizeof(int) * n);
+    /* (pixel indices as 32-bit unsigned numbers: an image has fewer than 2^32 pixels, but may have more than 2^31) */
+    uint32_t* stack = (uint32_t*)malloc(sizeof(uint32_t) * n);
     size_t top = 0;
     for (size_t i = 0; i < n; i++)
-        if (map[i] == 2) stack[top++] = (int)i;
+        if (map[i] == 2) stack[top++] = (uint32_t)i;
     while (top) {
-        int i = stack[--top];
-        int y = i / w, x = i % w;
+        uint32_t i = stack[--top];
+        int y = (int)(i / (uint32_t)w), x = (int)(i % (uint32_t)w);
         for (int ddy = -1; ddy <= 1; ddy++)
             for (int ddx = -1; ddx <= 1; ddx++) {
                 int yy = y + ddy, xx = x + ddx;
@@ -601,7 +602,7 @@ FR_API void fr_canny(const u8* src, size_t sp, u8* dst, size_t dp, int w, int h,
                 size_t j = (size_t)yy * w + xx;
                 if (map[j] == 0) {
                     map[j] = 2;
-                    stack[top++] = (int)j;
+                    stack[top++] = (uint32_t)j;
                 }
             }
     }
