@@ -1047,6 +1047,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         Ab.counts = point_counts + b0;
         Ab.accum = accum + (size_t)b0 * accum_stride;
         if (A.segmax) Ab.segmax = A.segmax + (size_t)b0 * numangle * A.nsegs;
+        if (A.rowcnt) Ab.rowcnt = A.rowcnt + (size_t)b0 * A.rowcnt_stride;
         const dim3 grid((unsigned)(A.groups * A.nseg), nb), block(VOTE_THREADS);
         Ab.items = (u32)A.groups * (u32)A.slices * (u32)nb;
         Ab.dbg_only_grp = -1;

@@ -1162,3 +1162,63 @@ def test_c_abi_from_a_plain_c_program():
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout + r.stderr
         assert r.stdout.count("identical to the CPU restatement") == 6 and "NO" not in r.stdout, r.stdout
+
+
+def test_more_images_than_a_grid_dimension_holds():
+    # 66000 tiny images in one call: launches that put the image index into a grid dimension are cut at 65535
+    # images, and every per-image array of the later pieces must start at the piece's first image (edge case:
+    # maximum batch sizes; the upload loop of receiveFile.py:22 has no bound on the number of files)
+    n, h, w = 66000, 20, 24
+    rng = np.random.default_rng(77)
+    bgr = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    bgr[:, 5:15, 3:20] //= 4
+    res = cv2.front_end_batch(bgr, thresh_val=128, vert_len=3, horiz_len=3, iterations=1, hough=True, hough_threshold=6)
+    acc = res.accum.cpu().numpy()
+    for i in list(range(3)) + list(range(65530, 65545)) + list(range(n - 3, n)):
+        g = fr.bgr2gray(bgr[i])
+        t = fr.threshold(g, 128, 255, 1)[1]
+        e = fr.canny(g, 50, 150)
+        assert np.array_equal(np.asarray(res.gray[i]), g) and np.array_equal(np.asarray(res.thresh[i]), t), i
+        assert np.array_equal(np.asarray(res.vlines[i]), fr.morphology_ex(t, 2, (1, 3), 1)), i
+        assert np.array_equal(np.asarray(res.hlines[i]), fr.morphology_ex(t, 2, (3, 1), 1)), i
+        assert np.array_equal(np.asarray(res.edges[i]), e), i
+        assert np.array_equal(acc[i], fr.hough_accum(e, 1.0, np.pi / 180)), i
+        want = fr.hough_lines(e, 1, np.pi / 180, 6)
+        assert (res.lines[i] is None) == (want is None) and (want is None or np.array_equal(res.lines[i], want)), i
+    segs = cv2.segments_batch(np.asarray(res.hlines))
+    for i in (0, 65535, 65536, n - 1):
+        assert [tuple(b) for b in segs[i]] == [tuple(b) for b in fr.external_boxes(np.asarray(res.hlines[i]))], i
+    # the single operations through the C ABI on the same number of images
+    from imageprocessing_amd import _native
+    from imageprocessing_amd._device import DevImage, stream_ptr, workspace
+
+    L = _native.lib()
+    st = stream_ptr()
+    src, out = DevImage.empty(n, h, w, 1), DevImage.empty(n, h, w, 1)
+    src.t[:, :, :w] = torch.from_numpy(np.ascontiguousarray(bgr[..., 1])).cuda()
+    ws = workspace(max(L.ipa_adaptive_threshold_workspace_bytes(w, h, n), L.ipa_gaussian_blur_workspace_bytes(w, h, n),
+                       L.ipa_morph_workspace_bytes(w, h, n), L.ipa_canny_workspace_bytes(w, h, n)))
+    io = (src.ptr, src.pitch, src.stride, out.ptr, out.pitch, out.stride, w, h, n)
+    wsa = (ws.data_ptr(), ws.numel(), st)
+    hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    otsu = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sample = (0, 65534, 65535, 65536, n - 1)
+    cases = [
+        ("threshold", lambda: L.ipa_threshold_u8(*io, 100.0, 255.0, 1, st), lambda g: fr.threshold(g, 100, 255, 1)[1]),
+        ("otsu", lambda: L.ipa_threshold_otsu_u8(*io, 255.0, 0, hist.data_ptr(), otsu.data_ptr(), st), lambda g: fr.threshold(g, 0, 255, 8)[1]),
+        ("erode 3x3", lambda: L.ipa_morph_u8(*io, 0, 3, 3, -1, -1, 1, 0, *wsa), lambda g: fr.morphology_ex(g, 0, (3, 3), 1)),
+        ("open 1x7", lambda: L.ipa_morph_u8(*io, 2, 1, 7, -1, -1, 1, 0, *wsa), lambda g: fr.morphology_ex(g, 2, (1, 7), 1)),
+        ("dilate 9x1", lambda: L.ipa_morph_u8(*io, 1, 9, 1, -1, -1, 1, 0, *wsa), lambda g: fr.morphology_ex(g, 1, (9, 1), 1)),
+        ("blur 5", lambda: L.ipa_gaussian_blur_u8(*io, 5, 5, 0.0, 0.0, 4, *wsa), lambda g: fr.gaussian_blur(g, (5, 5), 0)),
+        ("blur 9", lambda: L.ipa_gaussian_blur_u8(*io, 9, 9, 0.0, 0.0, 4, *wsa), lambda g: fr.gaussian_blur(g, (9, 9), 0)),
+        ("median 3", lambda: L.ipa_median_blur_u8(*io, 3, st), lambda g: fr.median_blur(g, 3)),
+        ("median 5", lambda: L.ipa_median_blur_u8(*io, 5, st), lambda g: fr.median_blur(g, 5)),
+        ("adaptive 11", lambda: L.ipa_adaptive_threshold_u8(*io, 255.0, 1, 0, 11, 2.0, *wsa), lambda g: fr.adaptive_threshold(g, 255, 1, 0, 11, 2)),
+        ("adaptive mean 5", lambda: L.ipa_adaptive_threshold_u8(*io, 255.0, 0, 1, 5, 3.0, *wsa), lambda g: fr.adaptive_threshold(g, 255, 0, 1, 5, 3)),
+        ("canny", lambda: L.ipa_canny_u8(*io, 50.0, 150.0, *wsa), lambda g: fr.canny(g, 50, 150)),
+    ]
+    for name, run, ref in cases:
+        assert run() == 0, (name, _native.last_error())
+        for i in sample:
+            gi = np.ascontiguousarray(bgr[i, ..., 1])
+            assert np.array_equal(out.t[i, :, :w].cpu().numpy(), ref(gi)), (name, i)
