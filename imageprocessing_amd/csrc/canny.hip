@@ -258,7 +258,9 @@ static_assert(WEAK == 1, "nms_pair encodes WEAK as 1");
 __device__ __forceinline__ u32 nms_pair(u32 m, u32 ax, u32 ay, u32 sgn, u32 CL, u32 CR, u32 PL, u32 Pc, u32 PR,
                                         u32 NL, u32 Nc, u32 NR, u32 low2, u32 high2, u32 span2)
 {
-    u32 out, t0, t1, t2, t3, t4;
+    // ax, ay and sgn are dead early and serve as temporaries afterwards (t4, t2, t3): the block needs two
+    // registers beyond its operands
+    u32 t0, t1;
     asm("v_pk_mul_lo_u16 %[t0], %[ax], 5 op_sel_hi:[1,0]\n\t"
         "v_pk_lshrrev_b16 %[t0], 8, %[t0] op_sel_hi:[0,1]\n\t"
         "v_pk_mad_u16 %[t0], %[ax], 53, %[t0] op_sel_hi:[1,0,1]\n\t"
@@ -270,42 +272,57 @@ __device__ __forceinline__ u32 nms_pair(u32 m, u32 ax, u32 ay, u32 sgn, u32 CL, 
         "v_pk_mad_u16 %[t0], %[ax], 2, %[t0] op_sel_hi:[1,0,1]\n\t"
         "v_pk_sub_u16 %[t0], %[ay], %[t0] clamp\n\t"
         "v_pk_min_u16 %[t0], %[t0], 1 op_sel_hi:[1,0]\n\t"           // vb = 1: vertical gradient
-        "v_pk_sub_u16 %[t2], 1, %[t1] op_sel_hi:[0,1]\n\t"
-        "v_pk_sub_u16 %[t2], %[t2], %[t0]\n\t"                       // 1 on the diagonals
+        "v_pk_sub_u16 %[ay], 1, %[t1] op_sel_hi:[0,1]\n\t"
+        "v_pk_sub_u16 %[ay], %[ay], %[t0]\n\t"                       // 1 on the diagonals
         "v_pk_sub_u16 %[t1], 0, %[t1] op_sel_hi:[0,1]\n\t"           // hb, vb -> 0xffff masks
         "v_pk_sub_u16 %[t0], 0, %[t0] op_sel_hi:[0,1]\n\t"
-        "v_pk_ashrrev_i16 %[t3], 15, %[sg] op_sel_hi:[0,1]\n\t"      // 0xffff: dx, dy of opposite sign
-        "v_bfi_b32 %[t4], %[t3], %[PR], %[PL]\n\t"
-        "v_bfi_b32 %[t4], %[t0], %[Pc], %[t4]\n\t"
-        "v_bfi_b32 %[t4], %[t1], %[CL], %[t4]\n\t"                   // neighbour that must be below m
-        "v_bfi_b32 %[t3], %[t3], %[NL], %[NR]\n\t"
-        "v_bfi_b32 %[t3], %[t0], %[Nc], %[t3]\n\t"
-        "v_bfi_b32 %[t3], %[t1], %[CR], %[t3]\n\t"                   // neighbour that must not exceed m
-        "v_pk_add_u16 %[t3], %[t3], %[t2]\n\t"                       //   (must be below m on the diagonals)
-        "v_pk_sub_u16 %[t3], %[t3], %[m] clamp\n\t"                  // != 0: fails
-        "v_pk_max_u16 %[t4], %[t4], %[low]\n\t"
-        "v_pk_sub_u16 %[t4], %[m], %[t4] clamp\n\t"
-        "v_pk_min_u16 %[t4], %[t4], 1 op_sel_hi:[1,0]\n\t"           // 1: m > neighbour and m > low
-        "v_pk_sub_u16 %[t4], %[t4], %[t3] clamp\n\t"                 // 1: local maximum
+        "v_pk_ashrrev_i16 %[sg], 15, %[sg] op_sel_hi:[0,1]\n\t"      // 0xffff: dx, dy of opposite sign
+        "v_bfi_b32 %[ax], %[sg], %[PR], %[PL]\n\t"
+        "v_bfi_b32 %[ax], %[t0], %[Pc], %[ax]\n\t"
+        "v_bfi_b32 %[ax], %[t1], %[CL], %[ax]\n\t"                   // neighbour that must be below m
+        "v_bfi_b32 %[sg], %[sg], %[NL], %[NR]\n\t"
+        "v_bfi_b32 %[sg], %[t0], %[Nc], %[sg]\n\t"
+        "v_bfi_b32 %[sg], %[t1], %[CR], %[sg]\n\t"                   // neighbour that must not exceed m
+        "v_pk_add_u16 %[sg], %[sg], %[ay]\n\t"                       //   (must be below m on the diagonals)
+        "v_pk_sub_u16 %[sg], %[sg], %[m] clamp\n\t"                  // != 0: fails
+        "v_pk_max_u16 %[ax], %[ax], %[low]\n\t"
+        "v_pk_sub_u16 %[ax], %[m], %[ax] clamp\n\t"
+        "v_pk_min_u16 %[ax], %[ax], 1 op_sel_hi:[1,0]\n\t"           // 1: m > neighbour and m > low
+        "v_pk_sub_u16 %[ax], %[ax], %[sg] clamp\n\t"                 // 1: local maximum
         "v_pk_sub_u16 %[t0], %[m], %[high] clamp\n\t"
         "v_pk_min_u16 %[t0], %[t0], 1 op_sel_hi:[1,0]\n\t"           // 1: above the high threshold
         "v_pk_mad_u16 %[t0], %[t0], %[span], 1 op_sel_hi:[1,1,0]\n\t"
-        "v_pk_mul_lo_u16 %[out], %[t4], %[t0]"
-        : [out] "=&v"(out), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
-        : [m] "v"(m), [ax] "v"(ax), [ay] "v"(ay), [sg] "v"(sgn), [CL] "v"(CL), [CR] "v"(CR), [PL] "v"(PL), [Pc] "v"(Pc),
+        "v_pk_mul_lo_u16 %[t0], %[ax], %[t0]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [ax] "+v"(ax), [ay] "+v"(ay), [sg] "+v"(sgn)
+        : [m] "v"(m), [CL] "v"(CL), [CR] "v"(CR), [PL] "v"(PL), [Pc] "v"(Pc),
           [PR] "v"(PR), [NL] "v"(NL), [Nc] "v"(Nc), [NR] "v"(NR), [low] "s"(low2), [high] "s"(high2), [span] "s"(span2));
-    return out;
+    return t0;
 }
+
+// Deferred non-maximum suppression (QUEUE).  On a diagram about 55 % of a wave's rows hold a magnitude above
+// the low threshold, but in such a row only about 11 of the 64 lanes do, and the suppression is half of
+// the vector instructions of a row.  Lanes with a candidate therefore put what the suppression needs
+// (the three magnitude rows of their columns -1 .. 4, |dx| of their four pixels, the signs of dx ^ dy,
+// their row and lane) into a per-wave LDS stack of 48-byte entries; when 64 entries wait, every lane
+// takes one and the suppression runs once with all lanes busy.  A lane writes the codes of its own
+// pixels unless it has queued them; queued pixels are written by the lane that takes the entry.
+// Rows in which NQ_DENSE or more lanes have a candidate are suppressed in place.
+constexpr int NQ_CAP = 104;    // at most 63 waiting + NQ_DENSE - 1 new; 4 waves x 104 x 48 B = 19968 B: 8 workgroups per CU
+constexpr int NQ_DENSE = 40;
+static_assert(63 + NQ_DENSE - 1 <= NQ_CAP, "queue capacity");
 
 // ROWS = rows per band (ROWS + 2 a multiple of 3): 64 for batches, 16 when a launch would otherwise have
 // too few waves to fill the chip (a wave walks its band row by row, so short bands also shorten the
 // longest dependent chain of the launch)
-template <bool EMIT, int ROWS>
+template <bool EMIT, int ROWS, bool QUEUE>
 __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int w, int h, int strips_x, int bands,
                                                       long long nwaves, int low, int high, int tiles_x, int tiles_y,
                                                       CannyWs W, PointSink sink)
 {
+    static_assert(!(EMIT && QUEUE), "the edge-list variant suppresses in place");
+    static_assert(!QUEUE || ROWS <= 128, "a queue entry holds the row within the band in 7 bits");
     __shared__ u32 s_pts[EMIT ? 4 : 1][EMIT ? 256 : 1];  // per wave: edge pixels waiting to be appended
+    __shared__ uint4 s_q[QUEUE ? 4 : 1][3][QUEUE ? NQ_CAP : 1];  // per wave: lanes waiting for their suppression
     // wave-uniform values are forced into scalar registers so that the row loop, the row
     // addresses and every "whole wave" decision below run on the scalar unit
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -360,6 +377,10 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         return *(const u32*)(simg + (size_t)off);
     };
     u8* const weak_row0 = W.has_weak + (size_t)b * tiles_y * tiles_x + x / TW;
+    u8* const weak_img = W.has_weak + (size_t)b * tiles_y * tiles_x;  // wave-uniform
+    uint4(*const q)[QUEUE ? NQ_CAP : 1] = s_q[QUEUE ? wv : 0];
+    u32 pending = 0;  // wave-uniform: entries on the stack
+    const int x_lane0 = sx * ST_COLS - 4;
 
     // gray rows yy-2 (a), yy-1 (bq) as 16-bit pairs (columns 0,1 and 2,3)
     s2 a0, a1, bq0, bq1;
@@ -381,6 +402,39 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     const u32 low2 = (u32)__builtin_amdgcn_readfirstlane(min(max(low, 0), 0x7fff) * 0x00010001);  // magnitudes never exceed 2040
     const u32 high2 = (u32)__builtin_amdgcn_readfirstlane(min(max(high, 0), 0x7fff) * 0x00010001);
     const u32 span2 = (u32)__builtin_amdgcn_readfirstlane((int)((255u - WEAK) * 0x00010001u));
+    // entries first .. first + count - 1 (count <= 64) leave the stack: lane i suppresses entry first + i
+    auto pop = [&](u32 first, u32 count) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((u32)lane < count) {
+            const uint4 e0 = q[0][first + lane], e1 = q[1][first + lane], e2 = q[2][first + lane];
+            const u32 info = e2.w;
+            const bool pz = (info & (1u << 16)) != 0, nz = (info & (1u << 17)) != 0;  // row above / below known to be zero
+            const u32 c01 = e0.x, c23 = e0.y, cO = e0.z;
+            const u32 p01 = pz ? 0u : e1.x, p23 = pz ? 0u : e1.y, pO = pz ? 0u : e1.z;
+            const u32 n01 = nz ? 0u : e2.x, n23 = nz ? 0u : e2.y, nO = nz ? 0u : e2.z;
+            // xO: column -1 in the high half, column 4 in the low half
+            const u32 cA = __builtin_amdgcn_alignbit(c01, cO, 16), cB = __builtin_amdgcn_alignbit(c23, c01, 16),
+                      cC = __builtin_amdgcn_alignbit(cO, c23, 16);
+            const u32 pA = __builtin_amdgcn_alignbit(p01, pO, 16), pB = __builtin_amdgcn_alignbit(p23, p01, 16),
+                      pC = __builtin_amdgcn_alignbit(pO, p23, 16);
+            const u32 nA = __builtin_amdgcn_alignbit(n01, nO, 16), nB = __builtin_amdgcn_alignbit(n23, n01, 16),
+                      nC = __builtin_amdgcn_alignbit(nO, n23, 16);
+            // |dy| = magnitude - |dx| (a column outside the image has magnitude 0 and yields 0 whatever |dy| is)
+            const u32 ax01 = e0.w, ax23 = e1.w;
+            const u32 ay01 = as_u32(as_s2(c01) - as_s2(ax01)), ay23 = as_u32(as_s2(c23) - as_s2(ax23));
+            // sign of dx ^ dy of pixel k in bit 8 k + 7 of info -> bit 15 of its 16-bit half
+            const u32 sg01 = __builtin_amdgcn_perm(0, info, 0x01010000u), sg23 = __builtin_amdgcn_perm(0, info, 0x03030202u);
+            const u32 k01 = nms_pair(c01, ax01, ay01, sg01, cA, cB, pA, p01, pB, nA, n01, nB, low2, high2, span2);
+            const u32 k23 = nms_pair(c23, ax23, ay23, sg23, cB, cC, pB, p23, pC, nB, n23, nC, low2, high2, span2);
+            const u32 codes = __builtin_amdgcn_perm(k23, k01, 0x06040200u);
+            const u32 ey = (u32)y0 + (info & 0x7fu), ex = (u32)x_lane0 + 4u * ((info >> 8) & 0x3fu);
+            *(u32*)(dimg + (size_t)(ey * dpitch + ex)) = codes;
+            if (codes & ~(codes >> 7) & 0x01010101u) weak_img[(ey / TH) * (u32)tiles_x + ex / TW] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    const u32 lane_info = (u32)lane << 8;
     // three gray rows are always in flight ahead of the row being consumed
     u32 gq[3];
 #pragma unroll
@@ -427,6 +481,14 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
             ax01 = as_u32(adx01); ax23 = as_u32(adx23); ay01 = as_u32(ady01); ay23 = as_u32(ady23);
             sg01 = as_u32(dx01) ^ as_u32(dy01);
             sg23 = as_u32(dx23) ^ as_u32(dy23);
+            if (QUEUE) {
+                // fewer registers across the loop: the high bytes of the four signs in one word (pixel k in byte k),
+                // and |dy| is recomputed as magnitude - |dx| where it is needed
+                sg01 = __builtin_amdgcn_perm(sg23, sg01, 0x07050301u);
+                sg23 = 0;
+                ay01 = 0;
+                ay23 = 0;
+            }
             mn.m01 = as_u32(adx01 + ady01) & cm01;
             mn.m23 = as_u32(adx23 + ady23) & cm23;
             mn.nL = from_lane_below(mn.m23);
@@ -436,8 +498,12 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         const int ry = yy - 2;
         if (it >= 2 && ry < y1) {
             u32 codes = 0;
+            bool queued = false;  // this lane's pixels of the row are on the stack
             // any magnitude of the row above the low threshold?  (per 16-bit half: max(m - low, 0))
-            if (!mc_zero && __any((pk_sub_sat_u16(mc.m01, low2) | pk_sub_sat_u16(mc.m23, low2)) != 0)) {
+            const bool cand = !mc_zero && (pk_sub_sat_u16(mc.m01, low2) | pk_sub_sat_u16(mc.m23, low2)) != 0 && (!QUEUE || writer);
+            const unsigned long long cmask = mc_zero ? 0ull : __ballot(cand);
+            const u32 ncand = (u32)__popcll(cmask);  // wave-uniform
+            if (ncand != 0 && (!QUEUE || ncand >= (u32)NQ_DENSE)) {
                 const MagRow zero = {0, 0, 0, 0};
                 const MagRow mpv = mp_zero ? zero : mp, mnv = mn_zero ? zero : mn;
                 // neighbour pairs: columns (-1,0), (1,2), (3,4) of the three rows
@@ -447,11 +513,31 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
                           pC = __builtin_amdgcn_alignbit(mpv.nR, mpv.m23, 16);
                 const u32 nA = __builtin_amdgcn_alignbit(mnv.m01, mnv.nL, 16), nB = __builtin_amdgcn_alignbit(mnv.m23, mnv.m01, 16),
                           nC = __builtin_amdgcn_alignbit(mnv.nR, mnv.m23, 16);
-                const u32 k01 = nms_pair(mc.m01, axc01, ayc01, sgc01, cA, cB, pA, mpv.m01, pB, nA, mnv.m01, nB, low2, high2, span2);
-                const u32 k23 = nms_pair(mc.m23, axc23, ayc23, sgc23, cB, cC, pB, mpv.m23, pC, nB, mnv.m23, nC, low2, high2, span2);
+                // (QUEUE: |dy| = magnitude - |dx|; a column outside the image has magnitude 0 and yields 0 whatever |dy| is)
+                const u32 ayd01 = QUEUE ? as_u32(as_s2(mc.m01) - as_s2(axc01)) : ayc01, ayd23 = QUEUE ? as_u32(as_s2(mc.m23) - as_s2(axc23)) : ayc23;
+                const u32 sgd01 = QUEUE ? __builtin_amdgcn_perm(0, sgc01, 0x01010000u) : sgc01, sgd23 = QUEUE ? __builtin_amdgcn_perm(0, sgc01, 0x03030202u) : sgc23;
+                const u32 k01 = nms_pair(mc.m01, axc01, ayd01, sgd01, cA, cB, pA, mpv.m01, pB, nA, mnv.m01, nB, low2, high2, span2);
+                const u32 k23 = nms_pair(mc.m23, axc23, ayd23, sgd23, cB, cC, pB, mpv.m23, pC, nB, mnv.m23, nC, low2, high2, span2);
                 codes = __builtin_amdgcn_perm(k23, k01, 0x06040200u);  // low byte of each 16-bit code
+            } else if (QUEUE && ncand != 0) {
+                // row within the band, lane, "row above / below is zero" and the four signs of dx ^ dy in one word
+                const u32 row_info = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(it - 2) | (mp_zero ? 1u << 16 : 0u) | (mn_zero ? 1u << 17 : 0u)));
+                if (cand) {
+                    const u32 pos = pending + __builtin_amdgcn_mbcnt_hi((u32)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)cmask, 0u));
+                    const u32 sgb = sgc01 & 0x80808080u;
+                    // column -1 (high half of nL) and column 4 (low half of nR) in one word
+                    q[0][pos] = make_uint4(mc.m01, mc.m23, __builtin_amdgcn_perm(mc.nL, mc.nR, 0x07060100u), axc01);
+                    q[1][pos] = make_uint4(mp.m01, mp.m23, __builtin_amdgcn_perm(mp.nL, mp.nR, 0x07060100u), axc23);
+                    q[2][pos] = make_uint4(mn.m01, mn.m23, __builtin_amdgcn_perm(mn.nL, mn.nR, 0x07060100u), sgb | lane_info | row_info);
+                    queued = true;
+                }
+                pending += ncand;
+                if (pending >= 64) {
+                    pop(pending - 64, 64);
+                    pending -= 64;
+                }
             }
-            if (writer) {
+            if (writer && !queued) {
                 *(u32*)(dimg + (size_t)((u32)ry * dpitch + (u32)x)) = codes;
                 // any WEAK byte (value 1, top bit clear) flags the 128x32 tile for the hysteresis
                 if (codes & ~(codes >> 7) & 0x01010101u) weak_row0[(u32)(ry / TH) * (u32)tiles_x] = 1;
@@ -481,6 +567,7 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
         mp = mc; mc = mn; mp_zero = mc_zero; mc_zero = mn_zero;
         axc01 = ax01; axc23 = ax23; ayc01 = ay01; ayc23 = ay23; sgc01 = sg01; sgc23 = sg23;
     }
+    if (QUEUE && pending != 0) pop(0, pending);
     flush(b);
 }
 
@@ -802,13 +889,19 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
             IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
             static const size_t pad = lds_pad_kib("IPA_PAD_CANNY");
             const dim3 grid((unsigned)((nwaves + 3) / 4));
-#define IPA_CANNY_STREAM(EMITV, ROWSV)                                                                              \
-    hipLaunchKernelGGL((k_canny_stream<EMITV, ROWSV>), grid, dim3(256), pad, st, src, dst, w, h, strips_x, bands, nwaves, \
-                       low, high, tiles_x, tiles_y, W, sink)
-            if (sink.pts && short_bands) IPA_CANNY_STREAM(true, ST_ROWS_SHORT);
-            else if (sink.pts) IPA_CANNY_STREAM(true, ST_ROWS);
-            else if (short_bands) IPA_CANNY_STREAM(false, ST_ROWS_SHORT);
-            else IPA_CANNY_STREAM(false, ST_ROWS);
+            static int queue = -1;  // IPA_CANNY_QUEUE=0: non-maximum suppression in place in every row (A/B)
+            if (queue < 0) {
+                const char* e = getenv("IPA_CANNY_QUEUE");
+                queue = e ? (atoi(e) != 0) : 1;
+            }
+#define IPA_CANNY_STREAM(EMITV, ROWSV, QUEUEV)                                                                      \
+    hipLaunchKernelGGL((k_canny_stream<EMITV, ROWSV, QUEUEV>), grid, dim3(256), pad, st, src, dst, w, h, strips_x, bands, \
+                       nwaves, low, high, tiles_x, tiles_y, W, sink)
+            if (sink.pts && short_bands) IPA_CANNY_STREAM(true, ST_ROWS_SHORT, false);
+            else if (sink.pts) IPA_CANNY_STREAM(true, ST_ROWS, false);
+            else if (short_bands) IPA_CANNY_STREAM(false, ST_ROWS_SHORT, false);
+            else if (queue) IPA_CANNY_STREAM(false, ST_ROWS, true);
+            else IPA_CANNY_STREAM(false, ST_ROWS, false);
 #undef IPA_CANNY_STREAM
         } else {
             IPA_REQUIRE(!sink.pts, IPA_ERR_ARG, "Canny: the LDS tile kernel cannot emit the edge-pixel list");
