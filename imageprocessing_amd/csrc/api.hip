@@ -99,13 +99,15 @@ IPA_EXPORT const char* ipa_last_error(void) { return g_err; }
 
 // ---- run-time options ---------------------------------------------------------
 // Schedule switches of the fused front-end.  Their defaults come from the environment the first
-// time one is needed (IPA_PIPELINE, IPA_OVERLAP, IPA_PHASED, IPA_HEAD_START); ipa_set_option changes
-// them for the calls that follow, from any thread.
+// time one is needed (IPA_PIPELINE, IPA_OVERLAP, IPA_PHASED, IPA_HEAD_START, IPA_CANNY_BANDS,
+// IPA_CANNY_QUEUE); ipa_set_option changes them for the calls that follow, from any thread.
+// canny_bands: -1 = rows per band of the Canny strip kernel by launch size, 16 / 64 = forced;
+// canny_queue: 0 = non-maximum suppression in place in every row (A/B; results do not differ).
 namespace {
-enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_COUNT };
-const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks"};
-const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START"};
-const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000};
+enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_CANNY_BANDS, OPT_CANNY_QUEUE, OPT_COUNT };
+const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks", "canny_bands", "canny_queue"};
+const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START", "IPA_CANNY_BANDS", "IPA_CANNY_QUEUE"};
+const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000, -1, 1};
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
 void options_init()
@@ -123,6 +125,9 @@ int option(int which)
     return g_opt[which].load(std::memory_order_relaxed);
 }
 }  // namespace
+
+int option_canny_bands() { return option(OPT_CANNY_BANDS); }
+int option_canny_queue() { return option(OPT_CANNY_QUEUE); }
 
 IPA_EXPORT int ipa_set_option(const char* name, int value)
 {

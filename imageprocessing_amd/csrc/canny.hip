@@ -883,17 +883,14 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
             if (!flags_cleared) IPA_HIP(hipMemsetAsync(W.has_weak, 0, (two_step ? 2 : 1) * align_up(ntiles, 256), st));
             const int strips_x = cdiv(w, ST_COLS);
             // short bands while 64-row bands would give fewer than 4096 waves (16 per CU)
-            const bool short_bands = (long long)strips_x * cdiv(h, ST_ROWS) * batch < 4096;
+            const int bands_opt = option_canny_bands();  // run-time option canny_bands: 16 / 64 force a band height
+            const bool short_bands = bands_opt == ST_ROWS_SHORT || (bands_opt != ST_ROWS && (long long)strips_x * cdiv(h, ST_ROWS) * batch < 4096);
             const int bands = cdiv(h, short_bands ? ST_ROWS_SHORT : ST_ROWS);
             const long long nwaves = (long long)strips_x * bands * batch;
             IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny: too many strips");
             static const size_t pad = lds_pad_kib("IPA_PAD_CANNY");
             const dim3 grid((unsigned)((nwaves + 3) / 4));
-            static int queue = -1;  // IPA_CANNY_QUEUE=0: non-maximum suppression in place in every row (A/B)
-            if (queue < 0) {
-                const char* e = getenv("IPA_CANNY_QUEUE");
-                queue = e ? (atoi(e) != 0) : 1;
-            }
+            const bool queue = option_canny_queue() != 0;  // run-time option canny_queue
 #define IPA_CANNY_STREAM(EMITV, ROWSV, QUEUEV)                                                                      \
     hipLaunchKernelGGL((k_canny_stream<EMITV, ROWSV, QUEUEV>), grid, dim3(256), pad, st, src, dst, w, h, strips_x, bands, \
                        nwaves, low, high, tiles_x, tiles_y, W, sink)

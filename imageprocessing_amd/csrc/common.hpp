@@ -205,6 +205,10 @@ struct PointSink {
 };
 
 size_t canny_ws_bytes(int w, int h, int batch);
+// run-time options (api.hip) read by the Canny launch
+int option_canny_bands();
+int option_canny_queue();
+
 // flags_cleared: the area canny_flag_area() names has been zeroed by the caller (on the same stream)
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
               PointSink sink, hipStream_t st, bool flags_cleared = false);

@@ -133,9 +133,16 @@ def ops_case(rng):
     if not np.array_equal(cv2.adaptiveThreshold(g, mv, meth, typ, blk, cc), fr.adaptive_threshold(g, mv, meth, typ, blk, cc)):
         return f"adaptiveThreshold {w}x{h} {mv} {meth} {typ} {blk} {cc}"
     lo, hi = float(rng.uniform(0, 300)), float(rng.uniform(0, 300))
-    e = cv2.Canny(g, lo, hi)
+    bands, queue = int(rng.choice([-1, 16, 64, 64])), int(rng.random() < 0.8)  # band height / deferred suppression of the strip kernel
+    cv2.set_option("canny_bands", bands)
+    cv2.set_option("canny_queue", queue)
+    try:
+        e = cv2.Canny(g, lo, hi)
+    finally:
+        cv2.set_option("canny_bands", -1)
+        cv2.set_option("canny_queue", 1)
     if not np.array_equal(e, fr.canny(g, lo, hi)):
-        return f"Canny {w}x{h} {lo} {hi}"
+        return f"Canny {w}x{h} {lo} {hi} bands={bands} queue={queue}"
     rho, theta = float(rng.choice([0.5, 1.0, 2.0, 3.0])), float(rng.choice([np.pi / 360, np.pi / 180, np.pi / 90, 0.05]))
     src = e if np.count_nonzero(e) else binary
     if not np.array_equal(cv2.hough_accumulator(src, rho, theta).cpu().numpy(), fr.hough_accum(src, rho, theta)):
@@ -527,6 +534,8 @@ def main():
         try:
             ipa.set_option("pipeline_chunks", chunks)
             ipa.set_option("phased", phased)
+            ipa.set_option("canny_bands", int(rng.choice([-1, 16, 64, 64])))
+            ipa.set_option("canny_queue", int(rng.random() < 0.8))
             r = ipa.front_end_batch(imgs, thresh_val=t, vert_len=vl, horiz_len=hl, iterations=it, canny=(lo, hi),
                                     blur=blur, hough=hough, edges=edges)
             acc = r.accum.cpu().numpy() if r.accum is not None else None

@@ -443,6 +443,37 @@ def test_canny_noisy_whiteboard():
     assert np.array_equal(cv2.Canny(g, 20, 60), fr.canny(g, 20, 60))
 
 
+@pytest.mark.parametrize("bands,queue", [(64, 1), (64, 0), (16, 1)])
+def test_canny_band_height_and_deferred_suppression(bands, queue):
+    # Small launches take 16-row bands and large ones 64-row bands whose non-maximum suppression is deferred
+    # through a per-wave stack (rows with many candidates are still suppressed in place): force every
+    # combination on images that fill the stack (noise, low thresholds), leave it nearly empty (a few
+    # strokes), end a band or a strip in the middle of the image, and on a batch.
+    cases = []
+    for h, w in ((70, 257), (64, 248), (66, 249), (131, 500), (200, 1500), (33, 128), (3, 4), (1, 700), (300, 5)):
+        cases.append((rand_gray(h * 3 + w, h, w), (50, 150)))
+        cases.append((rand_gray(h + w, h, w), (0, 300)))       # every pixel a candidate: rows suppressed in place
+        cases.append((smooth_gray(h + w * 5, h, w), (10, 40)))
+    cases.append((fr.bgr2gray(uml_like(9100, 700, 1300)), (50, 150)))           # sparse: a few lanes per row
+    cases.append((fr.bgr2gray(uml_like(9101, 500, 900, noise=6)), (20, 60)))
+    g = _weak_staircase(200, 1500)
+    g[18:24, 0:4] = 0
+    cases.append((g, (50, 150)))
+    cv2.set_option("canny_bands", bands)
+    cv2.set_option("canny_queue", queue)
+    try:
+        for g, (lo, hi) in cases:
+            a = cv2.Canny(g, lo, hi)
+            assert np.array_equal(a, fr.canny(g, lo, hi)), (g.shape, lo, hi)
+        bgr = np.stack([uml_like(9200 + i, 260, 700, noise=3 * (i % 2)) for i in range(9)])
+        r = cv2.front_end_batch(bgr, hough=False)
+        for i in range(9):
+            assert np.array_equal(r.edges[i], fr.canny(fr.bgr2gray(bgr[i]), 50, 150)), i
+    finally:
+        cv2.set_option("canny_bands", -1)
+        cv2.set_option("canny_queue", 1)
+
+
 # ------------------------------------------------------------------ Hough
 def _acc(img, rho=1, theta=np.pi / 180):
     return cv2.hough_accumulator(img, rho, theta).cpu().numpy()
