@@ -304,8 +304,8 @@ __device__ __forceinline__ u32 nms_pair(u32 m, u32 ax, u32 ay, u32 sgn, u32 CL, 
 // the vector instructions of a row.  Lanes with a candidate therefore put what the suppression needs
 // (the three magnitude rows of their columns -1 .. 4, |dx| of their four pixels, the signs of dx ^ dy,
 // their row and lane) into a per-wave LDS stack of 48-byte entries; when 64 entries wait, every lane
-// takes one and the suppression runs once with all lanes busy.  A lane writes the codes of its own
-// pixels unless it has queued them; queued pixels are written by the lane that takes the entry.
+// takes one and the suppression runs once with all lanes busy.  A lane writes zeros for pixels it has
+// queued; the lane that takes the entry overwrites them (after the row's own stores, see ZFILL).
 // Rows in which NQ_DENSE or more lanes have a candidate are suppressed in place.
 constexpr int NQ_CAP = 104;    // at most 63 waiting + NQ_DENSE - 1 new; 4 waves x 104 x 48 B = 19968 B: 8 workgroups per CU
 constexpr int NQ_DENSE = 40;
@@ -323,6 +323,10 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     static_assert(!QUEUE || ROWS <= 128, "a queue entry holds the row within the band in 7 bits");
     __shared__ u32 s_pts[EMIT ? 4 : 1][EMIT ? 256 : 1];  // per wave: edge pixels waiting to be appended
     __shared__ uint4 s_q[QUEUE ? 4 : 1][3][QUEUE ? NQ_CAP : 1];  // per wave: lanes waiting for their suppression
+    // Lanes that queue their pixels still write the row's zeros (whole 248-byte row pieces: masked stores
+    // leave partial cache lines, 10 % more HBM write traffic measured); the lane that takes the entry writes
+    // the codes later, after a wait for every store of the wave so far, so the two stores cannot swap.
+    constexpr bool ZFILL = QUEUE;
     // wave-uniform values are forced into scalar registers so that the row loop, the row
     // addresses and every "whole wave" decision below run on the scalar unit
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -429,6 +433,7 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
             const u32 k23 = nms_pair(c23, ax23, ay23, sg23, cB, cC, pB, p23, pC, nB, n23, nC, low2, high2, span2);
             const u32 codes = __builtin_amdgcn_perm(k23, k01, 0x06040200u);
             const u32 ey = (u32)y0 + (info & 0x7fu), ex = (u32)x_lane0 + 4u * ((info >> 8) & 0x3fu);
+            if (ZFILL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeros written for this row have arrived
             *(u32*)(dimg + (size_t)(ey * dpitch + ex)) = codes;
             if (codes & ~(codes >> 7) & 0x01010101u) weak_img[(ey / TH) * (u32)tiles_x + ex / TW] = 1;
         }
@@ -532,15 +537,15 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
                     queued = true;
                 }
                 pending += ncand;
-                if (pending >= 64) {
-                    pop(pending - 64, 64);
-                    pending -= 64;
-                }
             }
-            if (writer && !queued) {
+            if (writer && (ZFILL || !queued)) {
                 *(u32*)(dimg + (size_t)((u32)ry * dpitch + (u32)x)) = codes;
                 // any WEAK byte (value 1, top bit clear) flags the 128x32 tile for the hysteresis
                 if (codes & ~(codes >> 7) & 0x01010101u) weak_row0[(u32)(ry / TH) * (u32)tiles_x] = 1;
+            }
+            if (QUEUE && pending >= 64) {
+                pop(pending - 64, 64);
+                pending -= 64;
             }
             if (EMIT) {
                 // strong pixels (255) of this row -> the wave's buffer, in lane order per pixel column

@@ -71,6 +71,10 @@ size_t ipa_pitch_for(size_t row_bytes);
  *   "overlap"          [IPA_OVERLAP]     0 = a single chain keeps the opens on the caller's stream
  *   "phased"           [IPA_PHASED]      0 = chunks alternate between two streams also with a Hough stage
  *   "head_start_ticks" [IPA_HEAD_START]  head start of a resident vote kernel in 10 ns ticks
+ *   "canny_bands"      [IPA_CANNY_BANDS] rows per band of the Canny strip kernel: -1 = by launch size
+ *                                        (default), 16 or 64 = forced
+ *   "canny_queue"      [IPA_CANNY_QUEUE] 0 = non-maximum suppression in place in every row instead
+ *                                        of deferred through a per-wave LDS stack (64-row bands)
  * Results do not depend on any of them.  Settings apply to the calls that follow, from any thread. */
 int ipa_set_option(const char* name, int value);
 int ipa_get_option(const char* name, int* value);
