@@ -384,7 +384,7 @@ def main():
                                        "random_address_votes_per_s": round(rand_rate, 0),
                                        "frac_of_random_address_rate": round(rate / rand_rate, 4),
                                        "note": "180 votes per edge pixel, one ds_add_u32 lane each; ceiling = conflict-free rate; "
-                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.68 (profiles/pmc_r02c_4k_x1024_summary.txt)"}
+                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.68 (profiles/pmc_r02g_4k_x1024_summary.txt)"}
         cpu = None
         if not args.no_cpu:
             try:
