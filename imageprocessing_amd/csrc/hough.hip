@@ -214,6 +214,7 @@ struct VoteArgs {
     int slices;         // k_hough_vote_s: workgroups that share one (image, angle group); > 1: they add their bins to a zeroed accumulator
     int dbg_only_grp;   // experiments: only this angle group votes (-1 = all)
     u32 dbg_trip_mask;  // experiments: list trips wrapped into a small window (0xffffffff = off)
+    int comb;           // k_hough_vote_s: 1 = the lanes of a 16-lane group take list entries K apart, K by the angle (see load4)
     u32 items;        // k_hough_vote_s: (image, angle group) work items = groups * images of the launch
     // k_hough_vote_s: angles whose bin is the same for every pixel of an image row (bit n of rowdet: angle n; checked
     // on the host for this image size): they are voted from the per-row pixel counts, one add per row
@@ -449,10 +450,31 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     // arrives at 1.2 TB/s, one channel's worth per XCD), so every angle group starts a few trips
     // further into the list and wraps around: neighbours still find each other's lines in L2.
     const u32 rot = trips ? ((u32)grp * VOTE_STAGGER_TRIPS) % trips : 0u;
+    // Which four consecutive list entries of a trip's window (4 * NT entries) a lane takes.  The LDS serves an
+    // atomic instruction 16 lanes at a time, each group as slowly as its fullest bank.  On lists in raster order
+    // the entries of a horizontal stroke are consecutive pixels: with the 16 lanes of a group K entries apart,
+    // K |cos theta| in (1, 2], their bins are 16 different words less than 32 apart -- no conflict -- for every
+    // angle but 90 degrees (voted from the row counts).  Entries off such strokes behave like random ones as before.
+    // window entry = q * 16 K + r * K + s with r = lane within its group and (q, s) = divmod(4 * group + j, K).
+    u32 comb_k = 4;  // (the plain mapping is the comb with K = 4)
+    if (A.comb) {
+        const float ca = fabsf(cg[tg > 1 ? 1 : 0]);
+        comb_k = ca > 0.5f ? 2u : ca > 0.25f ? 4u : ca > 0.125f ? 8u : ca > 0.0625f ? 16u : ca > 0.03125f ? 32u : 64u;
+        comb_k = (u32)__builtin_amdgcn_readfirstlane((int)comb_k);
+        if (16u * comb_k > 4u * NT) comb_k = 4;  // (a window holds at least one comb)
+    }
+    const u32 lane16 = (u32)tid & 15u, grp16 = (u32)tid >> 4;
+    // two 8-byte loads: K >= 4: adjacent entries; K = 2: the second pair lies 32 entries further on
+    const u32 ent_a = comb_k >= 4 ? ((4u * grp16) / comb_k) * 16u * comb_k + lane16 * comb_k + ((4u * grp16) % comb_k)
+                                  : (2u * grp16) * 32u + lane16 * 2u;
+    const u32 pair_lo = ent_a >> 1, pair_hi = (comb_k >= 4 ? ent_a + 2u : ent_a + 32u) >> 1;
+    const uint2* const pts2 = (const uint2*)pts;
     auto load4 = [&](u32 trip) -> uint4 {
         u32 t = trip + rot;  // trip < trips
         t = t >= trips ? t - trips : t;
-        return pts4[(trip0 + (t & A.dbg_trip_mask)) * NT + tid];
+        const uint2* p2 = pts2 + (size_t)(trip0 + (t & A.dbg_trip_mask)) * (2u * NT);  // the trip's window
+        const uint2 lo = p2[pair_lo], hi = p2[pair_hi];
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
     };
     auto cast4 = [&](const uint4 cur) {
         const f2 x01 = {(float)(cur.x & 0xffffu), (float)(cur.y & 0xffffu)};
@@ -816,6 +838,21 @@ __global__ __launch_bounds__(256) void k_zero_i32(int32_t* __restrict__ accum, s
 // are compacted from `src` here.
 int hough_segments(int numrho) { return cdiv(numrho + 2, HOUGH_SEG); }
 
+// Lists in raster order (inside a compaction block) with the comb mapping of the vote kernel, or lists in the spread
+// order with the plain mapping?  Measured on 4K diagrams: raster + comb wins from about 16 images on (64 images: vote
+// 0.63 -> 0.54 ms, 1024 images: 9.06 -> 7.77 ms); few images, whose lists are cut into slices, are better off with
+// the spread order (1 image: 48 against 53 us).  IPA_VOTE_COMB=0 switches it off (A/B).  Both phases of a pass must
+// agree, so the rule uses nothing but the batch and the number of angles.
+static bool raster_lists(int batch, int numangle)
+{
+    static int comb = -1;
+    if (comb < 0) {
+        const char* e = getenv("IPA_VOTE_COMB");
+        comb = e ? atoi(e) : 1;
+    }
+    return comb != 0 && (long long)batch * cdiv(numangle, 4) >= 768;
+}
+
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
                     int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
                     int resident_wgs, hipStream_t st, bool counts_cleared)
@@ -870,11 +907,12 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
             }
             const int nw = nw_env == 4 || nw_env == 16 ? nw_env : ((long long)batch * cdiv(h, 4) < 16384 ? 16 : 4);  // rows per block
             const dim3 grid((unsigned)batch, (unsigned)cdiv(cpr, 64 * ROWS_PER_LANE), (unsigned)(cdiv(h, nw) | 1));
-            static int spread = -1;  // IPA_COMPACT_SPREAD=0 keeps raster order inside a block
-            if (spread < 0) {
+            static int spread_env = -2;  // IPA_COMPACT_SPREAD: 0 = raster order inside a block, 1 = spread order (default: by raster_lists)
+            if (spread_env == -2) {
                 const char* e = getenv("IPA_COMPACT_SPREAD");
-                spread = e ? atoi(e) : 1;
+                spread_env = e ? atoi(e) : -1;
             }
+            const int spread = spread_env >= 0 ? spread_env : (raster_lists(batch, numangle) ? 0 : 1);
             static const size_t pad = lds_pad_kib("IPA_PAD_COMPACT");
             if (nw == 16)
                 hipLaunchKernelGGL(k_hough_compact2<16>, grid, dim3(64, 16), pad, st, src, w, h, cpr, pts, pts_stride, cap, point_counts, spread,
@@ -977,6 +1015,7 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         remap = e ? atoi(e) : 1;
     }
     A.xcd_remap = remap;
+    A.comb = phase != HOUGH_VOTE_ONLY_FOREIGN_LISTS && raster_lists(batch, numangle) ? 1 : 0;
     A.nsegs = hough_segments(numrho);
     // Few large images: (image, angle group) alone gives too few workgroups to fill the chip, and one
     // angle whose votes pile up on a few bins (theta = 90 degrees on ruled paper) holds everything
