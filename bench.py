@@ -368,7 +368,7 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launch_ms": stages[dom]["ms"], "algorithmic_bytes_per_launch": alg[dom] * batch}
-            if dom == "hough_vote" and fe.hough:
+            if "hough_vote" in stages and stages["hough_vote"]["ms"] > 0 and fe.hough:
                 # The vote is bound by LDS atomics, not by HBM: also quote it against the LDS atomic rates measured on
                 # this chip with 16 waves per CU (scripts/micro/lds_rate.hip, lds_rand.hip; clocks at 2.4 GHz):
                 # a ds_add_u32 wave instruction takes 4.37 clk when its 64 addresses fall into different banks
@@ -376,15 +376,23 @@ def main():
                 # every instruction, which is what Hough bins of scattered edge pixels are (18.7e9).
                 props = torch.cuda.get_device_properties(dev)
                 votes = float(fe.point_counts[:batch].sum().item()) * fe.na
-                rate = votes / (stages[dom]["ms"] * 1e-3)
+                rate = votes / (stages["hough_vote"]["ms"] * 1e-3)
                 free_rate = 35.1e9 * props.multi_processor_count
                 rand_rate = 18.7e9 * props.multi_processor_count
-                roof["lds_atomics"] = {"votes_per_s": round(rate, 0), "ceiling_votes_per_s": round(free_rate, 0),
+                # (inside `roofline` while the vote is the dominant kernel, beside it otherwise)
+                vote_lds = {"votes_per_s": round(rate, 0), "ceiling_votes_per_s": round(free_rate, 0),
                                        "frac": round(rate / free_rate, 4),
                                        "random_address_votes_per_s": round(rand_rate, 0),
                                        "frac_of_random_address_rate": round(rate / rand_rate, 4),
                                        "note": "180 votes per edge pixel, one ds_add_u32 lane each; ceiling = conflict-free rate; "
-                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.68 (profiles/pmc_r02g_4k_x1024_summary.txt)"}
+                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.61 (profiles/pmc_r02h_4k_x1024_summary.txt; 0.68 before the comb mapping of the lanes)"}
+                if dom == "hough_vote":
+                    roof["lds_atomics"] = vote_lds
+                else:
+                    a2 = alg["hough_vote"] * batch / (stages["hough_vote"]["ms"] * 1e-3) / 1e9
+                    roof["runner_up"] = {"kernel": "hough_vote", "bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 4), "launch_ms": stages["hough_vote"]["ms"],
+                                         "lds_atomics": vote_lds}
         cpu = None
         if not args.no_cpu:
             try:
