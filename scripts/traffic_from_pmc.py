@@ -8,7 +8,7 @@ usage: traffic_from_pmc.py <pmc dir> <key e.g. 4kx128> [out json]"""
 import collections, csv, glob, json, os, re, sys
 
 STAGE_OF = {
-    "k_bgr2gray": "gray_thresh_pack", "k_bitmorph_v": "open_vertical", "k_bitmorph_h3": "open_horizontal",
+    "k_bgr2gray": "gray_thresh_pack", "k_bgr2gray_flat": "gray_thresh_pack", "k_bitmorph_v": "open_vertical", "k_bitmorph_h3": "open_horizontal",
     "k_bitmorph": "open_horizontal", "k_canny_stream": "canny_nms", "k_canny_nms": "canny_nms",
     "k_hyst_tiles": "canny_hysteresis", "k_hyst_final": "canny_hysteresis", "k_hough_compact": "hough_compact",
     "k_hough_vote": "hough_vote", "k_hough_vote_s": "hough_vote", "k_hough_peaks": "hough_peaks",
