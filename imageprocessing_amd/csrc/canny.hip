@@ -821,6 +821,71 @@ __global__ __launch_bounds__(256) void k_hyst_final(Plane dst, int w, int h, int
     }
 }
 
+// The same for launches of many tiles: a workgroup reads 256 tile flags at once, collects the flagged tiles in LDS
+// and then clears them four at a time (all four loads in flight) -- the loop above waits for one flag and then for
+// one tile per iteration, 540 times per workgroup at 1024 x 4K.
+__global__ __launch_bounds__(256) void k_hyst_final_batched(Plane dst, int w, int h, int tiles_x, int tiles_y, u32 ntiles,
+                                                            const u8* __restrict__ has_weak)
+{
+    __shared__ u32 s_list[256];
+    __shared__ u32 s_n;
+    const int lr = threadIdx.x >> 3, lc0 = (threadIdx.x & 7) * 16;
+    for (u32 base = blockIdx.x * 256u; base < ntiles; base += gridDim.x * 256u) {  // (uniform over the workgroup)
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const u32 mine = base + threadIdx.x;
+        if (mine < ntiles && has_weak[mine]) s_list[atomicAdd(&s_n, 1u)] = mine;
+        __syncthreads();
+        const u32 n = s_n;
+        for (u32 i = 0; i < n; i += 4) {
+            uint4* p[4];
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                p[k] = nullptr;
+                if (i + k < n) {
+                    const u32 tile = s_list[i + k];
+                    const int tx = tile % tiles_x;
+                    const u32 t2 = tile / tiles_x;
+                    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+                    const int iy = ty * TH + lr, ix0 = tx * TW + lc0;
+                    if (iy < h && ix0 < w) {
+                        p[k] = (uint4*)(dst.row(b, iy) + ix0);
+                        v[k] = *p[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!p[k]) continue;
+                u32 d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 keep = ((d[q] >> 7) & 0x01010101u) * 0xffu;  // keep a byte only if its top bit is set
+                    any |= (d[q] & ~keep) != 0;
+                    d[q] &= keep;
+                }
+                if (any) *p[k] = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+        }
+        __syncthreads();  // s_list and s_n are reused
+    }
+}
+
+// bytes that are still WEAK -> 0 in the flagged tiles
+static void launch_hyst_final(Plane dst, int w, int h, int tiles_x, int tiles_y, size_t ntiles, const u8* has_weak, hipStream_t st)
+{
+    // (the option that forces the large-launch form of the strip kernel forces this one too: tests on small images)
+    if (ntiles >= 256u * 1024u || option_canny_bands() == ST_ROWS) {
+        const unsigned grid = (unsigned)((ntiles + 255) / 256 < 4096 ? (ntiles + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_hyst_final_batched, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles, has_weak);
+    } else {
+        const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+        hipLaunchKernelGGL(k_hyst_final, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles, has_weak);
+    }
+}
+
 }  // namespace
 
 size_t canny_ws_bytes(int w, int h, int batch)
@@ -925,9 +990,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)batch), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
                            tiles_y, tiles_x, tiles_y, 1, 1, W1, sink, 1, -1);
         IPA_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-        hipLaunchKernelGGL(k_hyst_final, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles,
-                           (const u8*)W.has_weak);
+        launch_hyst_final(dst, w, h, tiles_x, tiles_y, ntiles, (const u8*)W.has_weak, st);
         IPA_LAUNCH_CHECK();
         return IPA_OK;
     }
@@ -978,9 +1041,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         IPA_HIP(hipStreamSynchronize(st));
         if (again <= (u32)r) break;  // launch r did not ask for launch r + 1
     }
-    const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-    hipLaunchKernelGGL(k_hyst_final, dim3(grid), dim3(256), 0, st, dst, w, h, tiles_x, tiles_y, (u32)ntiles,
-                       (const u8*)W.has_weak);
+    launch_hyst_final(dst, w, h, tiles_x, tiles_y, ntiles, (const u8*)W.has_weak, st);
     IPA_LAUNCH_CHECK();
     return IPA_OK;
 }
