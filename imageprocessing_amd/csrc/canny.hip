@@ -586,8 +586,22 @@ struct TileBits {
     u64 S, W;  // edge / WEAK masks of this lane's 64 pixels (bit i = pixel i)
 };
 
-// edge bytes of 64 consecutive pixels -> masks.  Pixels at or beyond `nvalid` are empty.
-__device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
+// edge bytes of 64 consecutive pixels, as loaded (pieces at or beyond `nvalid` are not read and stay zero)
+struct Raw64 {
+    uint4 v[4];
+};
+__device__ __forceinline__ Raw64 load_raw64(const u8* p, int nvalid)
+{
+    Raw64 r;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        r.v[q] = make_uint4(0, 0, 0, 0);
+        if (q * 16 < nvalid) r.v[q] = *(const uint4*)(p + 16 * q);
+    }
+    return r;
+}
+// -> masks.  Pixels at or beyond `nvalid` are empty.
+__device__ __forceinline__ TileBits bits_of_raw64(const Raw64& r, int nvalid)
 {
     TileBits t;
     t.S = 0;
@@ -595,9 +609,7 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
     if (nvalid <= 0) return t;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        if (q * 16 >= nvalid) break;
-        const uint4 v = *(const uint4*)(p + 16 * q);
-        const u32 d[4] = {v.x, v.y, v.z, v.w};
+        const u32 d[4] = {r.v[q].x, r.v[q].y, r.v[q].z, r.v[q].w};
         u32 s16 = 0, w16 = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -614,6 +626,16 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
         t.W &= m;
     }
     return t;
+}
+__device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
+{
+    if (nvalid <= 0) {
+        TileBits t;
+        t.S = 0;
+        t.W = 0;
+        return t;
+    }
+    return bits_of_raw64(load_raw64(p, nvalid), nvalid);
 }
 
 // Hysteresis on tiles.  One workgroup owns one image (or one region of a huge image) and
@@ -677,30 +699,59 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
         const u32 n = s_cnt[cur];
         if (n == 0) break;
         const int nxt = cur ^ 1;
-        for (;;) {
+        // What a tile visit reads, fetched one visit ahead: while a wave resolves a tile, the loads of its next
+        // one are under way (a visit is a chain of memory round trips otherwise).  Reading a neighbour's ring a
+        // little earlier is harmless: a neighbour whose rim changes afterwards puts this tile on the next round's list.
+        struct Visit {
+            int t;        // tile within the region, -1 = none
+            Raw64 own, ring;
+            u32 side, ring_side;
+        };
+        auto fetch = [&]() -> Visit {
+            Visit v;
             u32 i = 0;
             if (lane == 0) i = atomicAdd(&s_cursor, 1u);
             i = __shfl(i, 0);
-            if (i >= n) break;
-            const int t = s_list[cur][i];
+            v.t = i < n ? (int)s_list[cur][i] : -1;
+            v.side = v.ring_side = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v.own.v[q] = v.ring.v[q] = make_uint4(0, 0, 0, 0);
+            if (v.t < 0) return v;
+            const int lx = v.t % nx_t, ly = v.t / nx_t;
+            const int x0 = (tx_base + lx) * TW, y0 = (ty_base + ly) * TH;
+            const int iy = y0 + r, xh = x0 + 64 * hf;
+            if (iy < h && w - xh > 0) v.own = load_raw64(dst.row(b, iy) + xh, w - xh);
+            const int xs = hf ? x0 + TW : x0 - 1;
+            if (iy < h && xs >= 0 && xs < w) v.side = dst.row(b, iy)[xs];
+            const int ry_ = r == 0 ? y0 - 1 : y0 + TH;
+            if ((r == 0 || r == TH - 1) && ry_ >= 0 && ry_ < h) {
+                if (w - xh > 0) v.ring = load_raw64(dst.row(b, ry_) + xh, w - xh);
+                if (xs >= 0 && xs < w) v.ring_side = dst.row(b, ry_)[xs];
+            }
+            return v;
+        };
+        Visit nextv = fetch();
+        for (;;) {
+            const Visit v = nextv;
+            if (v.t < 0) break;  // (wave-uniform)
+            nextv = fetch();
+            const int t = v.t;
             const int lx = t % nx_t, ly = t / nx_t;
             const int x0 = (tx_base + lx) * TW, y0 = (ty_base + ly) * TH;
             const int iy = y0 + r, xh = x0 + 64 * hf;
             // own 64 pixels
             TileBits me;
             me.S = me.W = 0;
-            if (iy < h) me = load_bits64(dst.row(b, iy) + xh, w - xh);
+            if (iy < h) me = bits_of_raw64(v.own, w - xh);
             // the edge bit just outside this lane's end of the row (ring column)
-            const int xs = hf ? x0 + TW : x0 - 1;
-            u32 side = 0;
-            if (iy < h && xs >= 0 && xs < w) side = dst.row(b, iy)[xs] >> 7;
+            const u32 side = v.side >> 7;
             // ring rows: lanes of row 0 hold the row above the tile, lanes of row 31 the row below
             u64 ringS = 0;
             u32 ring_side = 0;
             const int ry_ = r == 0 ? y0 - 1 : y0 + TH;
             if ((r == 0 || r == TH - 1) && ry_ >= 0 && ry_ < h) {
-                ringS = load_bits64(dst.row(b, ry_) + xh, w - xh).S;
-                if (xs >= 0 && xs < w) ring_side = dst.row(b, ry_)[xs] >> 7;
+                ringS = bits_of_raw64(v.ring, w - xh).S;
+                ring_side = v.ring_side >> 7;
             }
             // horizontally dilated ring row (constant during the iteration)
             u64 ringH;
