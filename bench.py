@@ -385,7 +385,7 @@ def main():
                                        "random_address_votes_per_s": round(rand_rate, 0),
                                        "frac_of_random_address_rate": round(rate / rand_rate, 4),
                                        "note": "180 votes per edge pixel, one ds_add_u32 lane each; ceiling = conflict-free rate; "
-                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.61 (profiles/pmc_r02i_4k_x1024_summary.txt; 0.68 before the comb mapping of the lanes)"}
+                                               "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.61 (profiles/pmc_r02j_4k_x1024_summary.txt; 0.68 before the comb mapping of the lanes)"}
                 if dom == "hough_vote":
                     roof["lds_atomics"] = vote_lds
                 else:
