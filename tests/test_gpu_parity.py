@@ -475,6 +475,44 @@ def test_canny_band_height_and_deferred_suppression(bands, queue):
 
 
 # ------------------------------------------------------------------ Hough
+@pytest.mark.parametrize("rho,theta", [(1.0, np.pi / 180), (2.0, np.pi / 90), (0.5, np.pi / 360), (1.0, 0.05), (3.0, np.pi / 45)])
+def test_hough_accumulator_batches_through_the_c_abi(rho, theta):
+    # From about 17 images on (at 180 angles) the lists stay in raster order and the lanes of the vote kernel take
+    # entries K apart, K = 2 ... 64 by the angle: every spacing, on ruled images (long strokes: the case the mapping
+    # is made for), on noise, and with list lengths that are no multiple of a trip of the kernel.
+    from imageprocessing_amd import _native
+    from imageprocessing_amd._device import DevImage, stream_ptr, workspace
+
+    L = _native.lib()
+    h, w, n = 231, 517, 40
+    edges = []
+    for i in range(n):
+        if i % 3 == 2:
+            e = (np.random.default_rng(500 + i).random((h, w)) < 0.02 * (1 + i % 5)).astype(np.uint8) * 255
+        else:
+            e = fr.canny(fr.bgr2gray(uml_like(8100 + i, h, w, noise=0 if i % 2 else 4)), 50, 150)
+        edges.append(e)
+    edges[5][:] = 0            # an empty list
+    edges[6][100, :] = 255     # one full row and one full column
+    edges[6][:, 300] = 255
+    E = DevImage.empty(n, h, w, 1)
+    for i in range(n):
+        E.t[i, :h, :w] = torch.from_numpy(edges[i]).cuda()
+    na, nr = fr.hough_dims(w, h, rho, theta)
+    cells = (na + 2) * (nr + 2)
+    acc = torch.full((n, cells), -3, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ws = workspace(L.ipa_hough_workspace_bytes(w, h, n, 0))
+    rc = L.ipa_hough_accum_u8(E.ptr, E.pitch, E.stride, w, h, n, float(rho), float(theta), acc.data_ptr(), cells, None, 0,
+                              cnt.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr())
+    assert rc == 0, _native.last_error()
+    a = acc.cpu().numpy()
+    c = cnt.cpu().numpy()
+    for i in range(n):
+        assert c[i] == np.count_nonzero(edges[i]), i
+        assert np.array_equal(a[i].reshape(na + 2, nr + 2), fr.hough_accum(edges[i], rho, theta)), (i, rho, theta)
+
+
 def _acc(img, rho=1, theta=np.pi / 180):
     return cv2.hough_accumulator(img, rho, theta).cpu().numpy()
 
