@@ -5,8 +5,9 @@ Hough accumulator + peaks) on synthetic UML-like rasters.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size 4k|1080p|16k] [--no-cpu]
 
-N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``:
-one process per GPU.  By default the N > 1 workload is a FIXED total of 4096 4K diagrams (seeds
+N > 1 runs one process per GPU: either under ``python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N`` or, started plainly as ``python bench.py --gpus N``, by launching exactly that as a child process
+and passing its output and exit code through.  By default the N > 1 workload is a FIXED total of 4096 4K diagrams (seeds
 4000..8095) split by image index over the ranks (``sharding.shard_range``; 2048 / 1024 / 512 images
 per GPU at N = 2 / 4 / 8), each rank running the whole front-end on its block; ``--weak`` gives every
 rank 1024 images of its own instead.  No collective touches the data path: the only communication
@@ -136,6 +137,21 @@ def cpu_baseline(h, w, kw, seconds_target=12.0):
                       f"oracle/frontref.c with OpenMP ({threads} threads), {el:.1f} s"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children and wait for them."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,11 +174,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with "
-                  f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}",
-                  file=sys.stderr)
-            sys.exit(2)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # Started by itself: run the N ranks as CHILD processes of this one (torch.distributed.run), pass their
+            # output through and leave with their exit code.  Nothing here has touched the GPU yet - torch is not
+            # even imported - and this process never becomes another program.
+            sys.exit(launch_ranks(args.gpus))
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start one process per GPU",
+              file=sys.stderr)
+        sys.exit(2)
     h, w = SIZES[args.size]
     batch = args.batch or (1024 if args.size == "4k" else 1)
     kw = {"noise": 6, "gradient": True} if args.size == "16k" else {}
@@ -271,19 +290,27 @@ def main():
         from imageprocessing_amd.sharding import gather_to_rank0
 
         mine = checksums(fe, batch)
-        host_group = None
+        cpu_side = args.dist_backend != "nccl"
+        all_sums, err = None, None
         try:
-            host_group = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else None
+            host_group = dist.new_group(backend="gloo") if not cpu_side else None
             all_sums = gather_to_rank0(mine, total, rank, world, group=host_group)
+        except Exception as e:  # decided below by ALL ranks together: a rank must never switch collectives alone
+            err = e
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int64, device="cpu" if cpu_side else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             how = "host gather (gloo, point to point)"
-        except Exception as e:  # no usable host transport: the checksums travel as one device all_gather
+        else:
+            # no usable host transport on at least one rank: every rank sends its rows through one all_gather of
+            # the main group instead
             sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
-            pad = torch.zeros((max(sizes), 7), dtype=torch.int64, device=dev)
-            pad[:batch] = torch.from_numpy(mine).to(dev)
+            pad = torch.zeros((max(sizes), 7), dtype=torch.int64, device="cpu" if cpu_side else dev)
+            pad[:batch] = torch.from_numpy(mine).to(pad.device)
             out_t = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(out_t, pad)
             all_sums = np.concatenate([o[:n].cpu().numpy() for o, n in zip(out_t, sizes)]) if rank == 0 else None
-            how = f"device all_gather (host gather failed: {type(e).__name__})"
+            how = f"all_gather of the main group (host gather failed on a rank: {type(err).__name__ if err else 'elsewhere'})"
         if rank == 0:
             # a sample of the other ranks' images, recomputed here on this GPU from the same seeds
             from imageprocessing_amd.synth import synth_diagram
@@ -362,7 +389,10 @@ def main():
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(f"{args.size}x{batch}", {}).get(dom)
+                    # measured at 1024 images per launch; the kernels' traffic is proportional to the images
+                    tj = json.load(open(tf))
+                    per_image = tj.get("per_image", {}).get(args.size, {}).get(dom)
+                    traffic = round(per_image * batch) if per_image is not None else None
                 except Exception:
                     traffic = None
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

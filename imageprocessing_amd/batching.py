@@ -34,15 +34,25 @@ def decode_bgr(blob) -> Optional[np.ndarray]:
 
     Like cv2.imdecode(..., IMREAD_COLOR): palette and gray images are expanded, alpha is dropped, the
     EXIF orientation is applied, and 16-bit samples are reduced to their high byte (cv2 scales 16-bit
-    files by 1/256 when it converts them to 8 bits)."""
-    from PIL import Image, ImageOps
+    files by 1/256 when it converts them to 8 bits).  Pinned by a cv2-written file: the palette-PNG case
+    (tests/golden/output_bmp_pin.npz).  Not pinned by any file of the reference: EXIF orientation and
+    16-bit samples."""
+    from PIL import Image
 
     try:
         data = blob.read() if hasattr(blob, "read") else blob
         with Image.open(io.BytesIO(bytes(data))) as im:
-            im = ImageOps.exif_transpose(im)
+            im.load()
+            if im.getexif().get(0x0112, 1) not in (0, 1):  # an orientation tag that asks for a transposition
+                try:
+                    from PIL import ImageOps
+
+                    im = ImageOps.exif_transpose(im)
+                except Exception:  # some Pillow versions cannot transpose every mode: keep the stored orientation
+                    pass
             if im.mode.startswith("I;16") or im.mode == "I":
-                g = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)
+                # mode "I" is 32-bit signed (also what older Pillow reports for 16-bit PNG): clip to the 16-bit range
+                g = (np.clip(np.asarray(im).astype(np.int64), 0, 65535) >> 8).astype(np.uint8)
                 rgb = np.repeat(g[:, :, None], 3, axis=2)
             else:
                 rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)

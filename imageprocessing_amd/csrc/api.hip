@@ -440,26 +440,37 @@ int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t s
 
 // Events that order the helper streams.  They come from a per-thread pool that lives as long as the
 // thread: a wait enqueued on a stream refers to the record made before it, so an event may be
-// recorded again by a later call while earlier work is still in flight.
+// recorded again by a later call while earlier work is still in flight.  An event belongs to the device
+// that was current when it was created and can only be recorded on streams of that device, so a thread
+// keeps one pool per device it has used.
 struct EventPool {
     std::vector<hipEvent_t> ev;
     size_t next = 0;
-    ~EventPool()
+};
+struct EventPools {
+    std::map<int, EventPool> by_dev;
+    ~EventPools()
     {
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        for (auto& kv : by_dev)
+            for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
     }
 };
-thread_local EventPool g_events;
+thread_local EventPools g_events;
 struct Events {
+    int dev;  // the current device = the device of every stream of the call
+    explicit Events(int device) : dev(device) {}
     hipEvent_t make()
     {
-        EventPool& P = g_events;
+        EventPool& P = g_events.by_dev[dev];
         if (P.next == P.ev.size()) {
             if (P.ev.size() >= 64) {  // more than a call ever needs: start over
                 P.next = 0;
             } else {
                 hipEvent_t e = nullptr;
-                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return nullptr;
+                }
                 P.ev.push_back(e);
             }
         }
@@ -472,8 +483,11 @@ int stream_after(hipStream_t b, hipStream_t a, Events& E)
 {
     hipEvent_t e = E.make();
     IPA_REQUIRE(e != nullptr, IPA_ERR_HIP, "front_end: hipEventCreate failed");
-    IPA_HIP(hipEventRecord(e, a));
-    IPA_HIP(hipStreamWaitEvent(b, e, 0));
+    if (hipEventRecord(e, a) != hipSuccess || hipStreamWaitEvent(b, e, 0) != hipSuccess) {
+        // the caller may carry on without the helper stream: leave no sticky error for its next launch check
+        ipa_set_error("front_end: ordering two streams failed: %s", hipGetErrorString(hipGetLastError()));
+        return IPA_ERR_HIP;
+    }
     return IPA_OK;
 }
 
@@ -494,7 +508,7 @@ static int front_end_chunk(const Chunk& C, hipStream_t st, hipEvent_t after_gray
     if (after_gray) IPA_HIP(hipEventRecord(after_gray, st));
     // option overlap = 0: everything on the caller's stream
     hipStream_t so = option(OPT_OVERLAP) && !g_prof_on ? side_stream(0, C.dev, C.caller) : nullptr;  // stream of the opens
-    Events E;
+    Events E(C.dev);
     if (so && stream_after(so, st, E) != IPA_OK) so = nullptr;
     if (!so) so = st;
     rc = stage_opens(C, so);
@@ -551,7 +565,7 @@ static int front_end_impl(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_strid
     }
     if (nk == 1) return front_end_chunk(C[0], st);
 
-    Events E;
+    Events E(dev);
     int rc = stream_after(s2, st, E);  // the helper stream starts behind the work already queued on the caller's stream
     if (rc) return rc;
     // option phased = 0: the staggered schedule also when there is a Hough stage

@@ -1169,6 +1169,14 @@ IPA_EXPORT int ipa_canny_static_u8(const uint8_t* src, size_t src_pitch, size_t 
                 "Canny (static scratch): %d x %d x %d images need %zu bytes of scratch, the built-in array holds %zu "
                 "(use ipa_canny_u8 with a workspace)",
                 width, height, batch, need, CANNY_STATIC_BYTES);
+    if (stream) {  // the array of the CURRENT device is used: the stream must belong to it
+        int cur = -1;
+        hipDevice_t sd = -1;
+        if (hipGetDevice(&cur) == hipSuccess && hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess && (int)sd != cur) {
+            ipa_set_error("Canny (static scratch): the stream belongs to device %d but device %d is current", (int)sd, cur);
+            return IPA_ERR_ARG;
+        }
+    }
     void* ws = static_scratch_ptr();
     if (!ws) return IPA_ERR_HIP;
     return ipa_canny_u8(src, src_pitch, src_stride, dst, dst_pitch, dst_stride, width, height, batch, threshold1, threshold2,

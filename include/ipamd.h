@@ -259,7 +259,10 @@ int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
  * Batches that need more scratch than the array holds (ipa_canny_workspace_bytes() >
  * ipa_canny_static_max_bytes(): more than about 174 000 tiles of 128x32 pixels, e.g. 85
  * images of 3840x2160) are refused with IPA_ERR_WORKSPACE.  The device of `stream` must be
- * the current device.  All calls on one GPU share the array: calls that overlap in time on
+ * the current device (checked: IPA_ERR_ARG otherwise).  The call neither synchronises nor
+ * copies to the host - and is therefore safe under stream capture - only for images of at most
+ * 4096 tiles (e.g. 4096 x 4096 pixels); larger images make the hysteresis read one counter back per
+ * group of launches, as described for ipa_canny_u8.  All calls on one GPU share the array: calls that overlap in time on
  * one GPU (different streams or threads) race and must be serialised by the caller. */
 #define IPA_CANNY_STATIC_SCRATCH_BYTES ((size_t)512 * 1024)
 size_t ipa_canny_static_max_bytes(void);
@@ -331,8 +334,8 @@ int ipa_segments_u8(const uint8_t* mask, size_t mask_pitch, size_t mask_stride,
  * (lineDetection.py:12-19, "New Version/comparison.py":14,
  * newVersion3/detectHorizontalVerticalLines.py:64): the progressive probabilistic Hough transform.
  * The visits of the non-zero pixels are sequential by definition (pseudo-random order from
- * cv::RNG, every visit changes accumulator and mask), so one wave runs one image and a batch
- * runs as many waves side by side.  For image b, lines + b*max_lines*4 receives up to max_lines
+ * cv::RNG, every visit changes accumulator and mask), so one workgroup of sixteen waves runs one
+ * image (the waves share the bulk work inside a visit) and a batch runs as many workgroups side by side.  For image b, lines + b*max_lines*4 receives up to max_lines
  * segments (x0, y0, x1, y1) in the order cv2 finds them; counts[b] receives their number (may
  * exceed max_lines: retry with more room) or -1 when the image has more non-zero pixels than
  * `max_points` (0 = width*height, always enough).  The accumulator has numangle x numrho cells

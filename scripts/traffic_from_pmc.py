@@ -47,6 +47,9 @@ def main():
     if os.path.exists(out):
         data = json.load(open(out))
     data[key] = {s: round(v) for s, v in stage.items()}
+    m = re.fullmatch(r"(\w+?)x(\d+)", key)
+    if m:  # bytes per image and stage: what bench.py scales by its own batch
+        data.setdefault("per_image", {})[m.group(1)] = {s: v / int(m.group(2)) for s, v in stage.items()}
     data.setdefault("_note", "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), rocprofv3 --pmc, separate passes")
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     for k, n, f, w in rows:

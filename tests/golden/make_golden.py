@@ -19,6 +19,19 @@ Origins (every expected value is labelled):
   (NewVersion2/img2UML.py:16-17): BMP stores the BGR pixels cv2 decoded, so it pins what
   ``cv2.imread`` / ``cv2.imdecode(IMREAD_COLOR)`` makes of that palette PNG.  The fixture keeps the
   PNG file itself (a 15 kB data file), the SHA-256 of output.bmp's pixel array and a 96x128 crop.
+* ``arrow_pin.npz`` -- origin ``cv2-artefact``.  thresh_image.png / arrow_image.png at the root of the
+  reference (2000 x 1480, values {0, 255}) were written by newVersion3/detect_arrowv2.py:126,146 (an earlier run
+  on an un-shipped input): ``arrow`` = the filled contours (RETR_TREE, drawContours thickness -1, :13,33) of
+  those components of ``cv2.dilate(thresh, getStructuringElement(MORPH_RECT, (2, 2)))`` (:10-11) that have a
+  deep convexity defect.  Whatever the selection was, every drawn component is a whole 8-connected component of
+  the dilated image with its holes filled, so
+  ``fill_holes(components of dilate2x2(thresh) that meet arrow) == arrow`` must hold pixel for pixel.  It does
+  with the window offsets {-1, 0} (anchor (1, 1) and ignored out-of-image samples); with offsets {0, +1} 9002
+  pixels differ.  The pair therefore pins the anchor of an even-sized kernel and the border rule of cv2.dilate.
+  The fixture keeps both images whole as packed bits (the invariant is about whole components) with their SHA-256.
+* ``images/*.png`` -- the reference's own input diagrams (images/*.png, 41 files, 0.85 MB; the JPEG and the WebP
+  are left out), copied as data files: what the scripts and the ``__main__`` blocks of the parsers load by
+  hard-coded path.  Inputs only; expected outputs are ``restatement`` values computed in the tests.
 """
 import hashlib
 import os
@@ -70,6 +83,22 @@ def main():
     np.savez_compressed(f"{OUT}/output_bmp_pin.npz", shape=np.array(bmp.shape), sha256=np.frombuffer(
         hashlib.sha256(np.ascontiguousarray(bmp).tobytes()).digest(), np.uint8), crop=bmp[300:396, 500:628].copy())
     print("output.bmp", bmp.shape, hashlib.sha256(np.ascontiguousarray(bmp).tobytes()).hexdigest())
+    th = np.asarray(Image.open(f"{REF}/thresh_image.png").convert("L"))
+    ar = np.asarray(Image.open(f"{REF}/arrow_image.png").convert("L"))
+    assert th.shape == ar.shape and set(np.unique(th)) <= {0, 255} and set(np.unique(ar)) <= {0, 255}
+    np.savez_compressed(
+        f"{OUT}/arrow_pin.npz", shape=np.array(th.shape),
+        thresh_bits=np.packbits(th > 0, axis=1), arrow_bits=np.packbits(ar > 0, axis=1),
+        thresh_sha256=np.frombuffer(hashlib.sha256(th.tobytes()).digest(), np.uint8),
+        arrow_sha256=np.frombuffer(hashlib.sha256(ar.tobytes()).digest(), np.uint8))
+    print("arrow pin", th.shape, int((th > 0).sum()), int((ar > 0).sum()))
+    os.makedirs(f"{OUT}/images", exist_ok=True)
+    n = 0
+    for name in sorted(os.listdir(f"{REF}/images")):
+        if name.lower().endswith(".png"):
+            shutil.copyfile(f"{REF}/images/{name}", f"{OUT}/images/{name.replace(' - Copy', '_copy')}")
+            n += 1
+    print("input diagrams", n)
 
 
 if __name__ == "__main__":

@@ -28,6 +28,36 @@ def test_bitwise_not_kat(gray_kat):
     assert np.array_equal(fr.bitwise_not(gray_kat["bgr"]), gray_kat["inverted_bgr"])
 
 
+def test_dilate_2x2_anchor_and_border_pinned_by_cv2_artefact(arrow_pin):
+    # cv2-artefact: newVersion3/detect_arrowv2.py:10-11,33,126-146 (see tests/golden/make_golden.py)
+    from tests.conftest import arrow_invariant_mismatches
+
+    thresh, arrow = arrow_pin
+    for d in (fr.morphology_ex(thresh, 1, (2, 2), 1), nr.morph(thresh, 1, (2, 2), 1)):
+        assert set(np.unique(d)) <= {0, 255}
+        assert arrow_invariant_mismatches(d, arrow) == 0
+    # control: the other possible window of an even kernel (offsets {0, +1}) is NOT what cv2 did
+    other = fr.morphology_ex(thresh, 1, (2, 2), 1, anchor=(0, 0))
+    assert arrow_invariant_mismatches(other, arrow) > 1000
+    # the border rule: out-of-image samples never win (a dilation never lights a pixel from outside)
+    assert fr.morphology_ex(np.zeros((5, 7), np.uint8), 1, (2, 2), 1).sum() == 0
+
+
+def test_restatements_agree_on_the_reference_diagrams():
+    # restatement: the C and the numpy statements of the parsers' prefix on a sample of the reference's own inputs
+    from tests.conftest import load_reference_diagram, reference_diagrams
+
+    for name, ts in reference_diagrams()[::6]:
+        bgr = load_reference_diagram(name)
+        g = fr.bgr2gray(bgr)
+        assert np.array_equal(g, nr.bgr2gray(bgr)), name
+        for t in ts:
+            th = fr.threshold(g, t, 255, 1)[1]
+            assert np.array_equal(th, nr.threshold(g, t, 255, 1)[1]), name
+            assert np.array_equal(fr.morphology_ex(th, 2, (1, 15), 2), nr.morph(th, 2, (1, 15), 2)), name
+            assert np.array_equal(fr.morphology_ex(th, 2, (15, 1), 2), nr.morph(th, 2, (15, 1), 2)), name
+
+
 # ---------------------------------------------------------------- analytic
 def test_gray_primaries():
     px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0]]], np.uint8)
