@@ -367,6 +367,7 @@ def main():
             "open_horizontal": 1.125 * h * w,
             "gaussian_blur": 2.0 * h * w,
             "canny_nms": 2.0 * h * w,                 # gray in + edges out
+            "gray_thresh_canny": 6.0 * h * w,         # BGR in (3) + gray, thresh and edge codes out (3): the fused kernel
             "canny_hysteresis": 0.0,
             "hough_compact": 1.0 * h * w,             # edges in (the point list is << 1 B/px)
             "hough_vote": acc_bytes,                  # accumulator written once

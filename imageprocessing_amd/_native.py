@@ -80,9 +80,11 @@ class NativeLibraryError(ImportError):
 
 
 def lib():
-    """The loaded library (loads it on first use; raises if it is not built)."""
-    global _lib
+    """The loaded library (loads it on first use; raises if it is not built).  IPA_LIB_PATH names another build
+    of the same library (A/B measurements of kernel variants in one session)."""
+    global _lib, SO_PATH
     if _lib is None:
+        SO_PATH = os.environ.get("IPA_LIB_PATH") or SO_PATH
         if not os.path.exists(SO_PATH):
             raise NativeLibraryError(
                 f"{SO_PATH} is missing: build it with `make -C imageprocessing_amd/csrc` "

@@ -1,6 +1,7 @@
 // Library-level entry points: version, error text, pitch helper and the fused
 // front-end that chains the per-op launchers on one stream.
 #include "common.hpp"
+#include "gray_core.hpp"
 
 #include <math.h>
 #include <stdlib.h>
@@ -71,7 +72,7 @@ IPA_EXPORT int ipa_profile_stage_count(void) { return PROF_NSTAGES; }
 IPA_EXPORT const char* ipa_profile_stage_name(int stage)
 {
     static const char* names[PROF_NSTAGES] = {"gray_thresh_pack", "open_vertical",  "open_horizontal",
-                                              "gaussian_blur",    "canny_nms",      "canny_hysteresis",
+                                              "gaussian_blur",    "canny_nms",      "gray_thresh_canny", "canny_hysteresis",
                                               "hough_compact",    "hough_vote",     "hough_peaks"};
     return (stage >= 0 && stage < PROF_NSTAGES) ? names[stage] : "";
 }
@@ -103,11 +104,16 @@ IPA_EXPORT const char* ipa_last_error(void) { return g_err; }
 // IPA_CANNY_QUEUE); ipa_set_option changes them for the calls that follow, from any thread.
 // canny_bands: -1 = rows per band of the Canny strip kernel by launch size, 16 / 64 = forced;
 // canny_queue: 0 = non-maximum suppression in place in every row (A/B; results do not differ).
+// canny_wide: -1 = the kernel that writes whole aligned lines (fused with the BGR conversion in the front-end
+// pass) for launches large enough to fill the chip, 0 = never (default), 4 / 8 = always, with that many pixel pairs per lane.
+// vote_gray: 0 (default) = in the phased schedule the gray conversion of chunk c + 1 runs as a kernel of its own on the
+// helper stream beside a resident vote grid, 1 = it is done by spare waves of the vote kernel of chunk c (one launch),
+// 2 = as 1, with the opens of a chunk beside that chunk's vote instead of beside its Canny kernels.
 namespace {
-enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_CANNY_BANDS, OPT_CANNY_QUEUE, OPT_COUNT };
-const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks", "canny_bands", "canny_queue"};
-const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START", "IPA_CANNY_BANDS", "IPA_CANNY_QUEUE"};
-const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000, -1, 1};
+enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_CANNY_BANDS, OPT_CANNY_QUEUE, OPT_CANNY_WIDE, OPT_VOTE_GRAY, OPT_COUNT };
+const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks", "canny_bands", "canny_queue", "canny_wide", "vote_gray"};
+const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START", "IPA_CANNY_BANDS", "IPA_CANNY_QUEUE", "IPA_CANNY_WIDE", "IPA_VOTE_GRAY"};
+const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000, -1, 1, 0, 0};
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
 void options_init()
@@ -128,6 +134,7 @@ int option(int which)
 
 int option_canny_bands() { return option(OPT_CANNY_BANDS); }
 int option_canny_queue() { return option(OPT_CANNY_QUEUE); }
+int option_canny_wide() { return option(OPT_CANNY_WIDE); }
 
 IPA_EXPORT int ipa_set_option(const char* name, int value)
 {
@@ -316,6 +323,7 @@ struct Chunk {
     u8* blur_plane;
     size_t bpw, bsw;
     bool precleared;  // the gray kernel zeroes the Canny tile flags and the Hough point counts (short passes)
+    int wide_np;      // > 0: gray, threshold, bit plane and Canny's non-maximum suppression in one kernel (pixel pairs per lane)
 };
 
 bool fused_points();
@@ -360,13 +368,19 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
     // short passes (a few images): the few kilobytes of flags and counters are zeroed inside the gray kernel
     static const int preclear = getenv("IPA_PRECLEAR") ? atoi(getenv("IPA_PRECLEAR")) : 1;  // 0: separate memsets (A/B)
     C.precleared = preclear && edges != nullptr && !fused_points() && canny_ws_bytes(width, height, batch) <= 64 * 1024 && batch <= 1024;
+    // one kernel from BGR to the Canny codes when nothing sits between the gray plane and Canny
+    C.wide_np = 0;
+    if (edges != nullptr && !blur5x5 && !fused_points()) {
+        const int np = canny_wide_np(width, height, batch);
+        if (np && canny_wide_fits(width, height, bgr_pitch, plane_pitch, plane_pitch, plane_pitch, np)) C.wide_np = np;
+    }
     return IPA_OK;
 }
 
-// gray + THRESH_BINARY_INV plane + its bit plane, one pass over the BGR input
+// gray + THRESH_BINARY_INV plane + its bit plane, one pass over the BGR input; with C.wide_np the same kernel
+// also does Canny's gradient and non-maximum suppression (the edge plane then holds the codes 0 / WEAK / 255)
 int stage_gray(const Chunk& C, hipStream_t st)
 {
-    ProfScope ps(PROF_GRAY_THRESH, st);
     ClearList clr = {{nullptr, nullptr, nullptr}, {0, 0, 0}};
     if (C.precleared) {
         canny_flag_area(C.width, C.height, C.batch, C.canny_ws, &clr.p[0], &clr.n[0]);
@@ -376,6 +390,19 @@ int stage_gray(const Chunk& C, hipStream_t st)
             hough_rowcount_area(C.width, C.height, C.batch, C.max_points, C.hough_ws, &clr.p[2], &clr.n[2]);
         }
     }
+    if (C.wide_np) {
+        // the tile flags this kernel raises itself (and the marks behind them) are zeroed before it starts
+        u32* fp = nullptr;
+        u32 fn = 0;
+        canny_flag_area(C.width, C.height, C.batch, C.canny_ws, &fp, &fn);
+        IPA_HIP(hipMemsetAsync(fp, 0, (size_t)fn * 4, st));
+        clr.p[0] = nullptr;
+        clr.n[0] = 0;
+        ProfScope ps(PROF_GRAY_CANNY, st);
+        return launch_canny_wide(true, C.wide_np, C.B, C.G, C.T, C.bits, C.bpw, C.bsw, C.E, C.width, C.height, C.batch, C.tv, 255, 1,
+                                 C.lo, C.hi, C.canny_ws, clr, st);
+    }
+    ProfScope ps(PROF_GRAY_THRESH, st);
     return launch_bgr2gray(C.B, C.G, C.T, C.bits, C.bpw, C.bsw, C.width, C.height, C.batch, C.tv, 255, 1, st, clr);
 }
 
@@ -422,20 +449,22 @@ int stage_edges(const Chunk& C, bool with_lists, hipStream_t st)
         sink = hough_point_sink(C.width, C.height, C.max_points, C.point_counts, C.hough_ws);
         IPA_HIP(hipMemsetAsync(C.point_counts, 0, sizeof(int32_t) * (size_t)C.batch, st));
     }
-    rc = run_canny(csrc, C.E, C.width, C.height, C.batch, C.lo, C.hi, C.canny_ws, C.L.canny_bytes, sink, st, C.precleared);
+    rc = run_canny(csrc, C.E, C.width, C.height, C.batch, C.lo, C.hi, C.canny_ws, C.L.canny_bytes, sink, st,
+                   C.precleared || C.wide_np != 0, C.wide_np != 0);
     if (rc || !C.accum || !with_lists || fused_points()) return rc;
     return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
                            C.point_counts, C.hough_ws, C.L.hough_bytes, HOUGH_COMPACT_ONLY, 0, st, C.precleared);
 }
 
-// lists_ready: stage_edges has already made the edge-pixel lists
-int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t st)
+// lists_ready: stage_edges has already made the edge-pixel lists; job: a gray conversion that may ride along
+int stage_vote(const Chunk& C, bool lists_ready, int resident_wgs, hipStream_t st, const GrayJob* job = nullptr, bool* job_done = nullptr)
 {
+    if (job_done) *job_done = false;
     if (!C.accum) return IPA_OK;
     return run_hough_accum(C.E, C.width, C.height, C.batch, 1.0, M_PI / 180, C.accum, C.accum_stride, C.seg_max, C.max_points,
                            C.point_counts, C.hough_ws, C.L.hough_bytes,
                            fused_points() ? HOUGH_VOTE_ONLY_FOREIGN_LISTS : (lists_ready ? HOUGH_VOTE_ONLY : HOUGH_ALL), resident_wgs,
-                           st, C.precleared);
+                           st, C.precleared, job, job_done);
 }
 
 // Events that order the helper streams.  They come from a per-thread pool that lives as long as the
@@ -583,18 +612,50 @@ static int front_end_impl(const uint8_t* bgr, size_t bgr_pitch, size_t bgr_strid
         if (!rc) rc = stream_after(s2, st, E);
         if (!rc) rc = stage_opens(C[0], s2);
         if (!rc) rc = stage_blur(C[0], st);
+        int opens_due = -1;  // chunk whose opens wait for the next vote phase (option vote_gray = 2)
         for (int c = 0; c < nk && !rc; c++) {
             rc = stage_edges(C[c], true, st);
             if (rc) break;
             const bool more = c + 1 < nk;
-            if (more) {
+            if (opens_due == c) {  // beside this chunk's vote instead of beside its Canny kernels
                 rc = stream_after(s2, st, E);
+                if (!rc) rc = stage_opens(C[c], s2);
                 if (rc) break;
-                hipLaunchKernelGGL(k_head_start, dim3(1), dim3(1), 0, s2, (unsigned)head_ticks);
+                opens_due = -1;
             }
-            rc = stage_vote(C[c], true, more ? cus : 0, st);
+            // The binarisation of chunk c + 1 (bound by HBM) beside the vote of chunk c (LDS atomics, vector instructions):
+            // as spare waves inside the vote kernel, or else as a kernel of its own on the helper stream.
+            bool voted = false, rode = false;
+            if (more && option(OPT_VOTE_GRAY)) {
+                const Chunk& N = C[c + 1];
+                GrayJob job;
+                if (!N.wide_np && !N.precleared &&
+                    gray_job_make(&job, N.B, N.G, N.T, N.bits, N.bpw, N.bsw, N.width, N.height, N.batch, N.tv, 255, 1)) {
+                    rc = stage_vote(C[c], true, 0, st, &job, &rode);
+                    voted = true;
+                }
+            }
+            if (!voted) {
+                if (more) {
+                    rc = stream_after(s2, st, E);
+                    if (rc) break;
+                    hipLaunchKernelGGL(k_head_start, dim3(1), dim3(1), 0, s2, (unsigned)head_ticks);
+                }
+                rc = stage_vote(C[c], true, more ? cus : 0, st);
+            }
             if (rc || !more) break;
-            rc = stage_gray(C[c + 1], s2);
+            if (rode) {
+                rc = stage_blur(C[c + 1], st);
+                if (option(OPT_VOTE_GRAY) == 2) {
+                    opens_due = c + 1;
+                    continue;
+                }
+                if (!rc) rc = stream_after(s2, st, E);  // the opens read the bit plane
+                if (!rc) rc = stage_opens(C[c + 1], s2);
+                continue;
+            }
+            if (voted) rc = stream_after(s2, st, E);  // (the vote kernel did not take the job: the conversion follows it)
+            if (!rc) rc = stage_gray(C[c + 1], s2);
             if (!rc) rc = stage_blur(C[c + 1], s2);  // bound by HBM like the gray kernel: beside the vote as well
             if (!rc) rc = stream_after(st, s2, E);  // the next Canny needs the gray (blurred) plane, not the opens
             if (!rc) rc = stage_opens(C[c + 1], s2);

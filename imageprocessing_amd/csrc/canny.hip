@@ -576,6 +576,450 @@ __global__ __launch_bounds__(256) void k_canny_stream(Plane src, Plane dst, int 
     flush(b);
 }
 
+// ---- wide variant: whole aligned lines, optionally fused with BGR -> gray / threshold / bit plane ----------
+// One wave walks a strip of 64 * PX pixels (PX = 2 NP pixels per lane: 512 or 1024 columns) downwards and
+// writes every plane as whole aligned lines: a row piece of a wave is 512 or 1024 contiguous bytes that start
+// at a multiple of their length, so no cache line is shared with the neighbouring strip (the 248-byte pieces
+// of k_canny_stream are).  The price is the halo: the two columns left and right of the strip are loaded and
+// converted redundantly by lanes 0 and 63 (a pair of pixels each), and the band's two rows above and below
+// are read again by the neighbouring bands.
+//   BGR_IN: the source is the interleaved BGR image; gray, thresholded plane and bit plane of the band's own
+//           rows are written on the way (the arithmetic of k_bgr2gray_flat), so the gray plane is never read
+//           back.  Otherwise the source is a gray plane (cv2.Canny alone).
+// Non-maximum suppression is always deferred: a group of four pixels with a magnitude above the low threshold
+// goes onto the wave's LDS stack (the entry format of k_canny_stream plus the group's number) and 64 entries
+// at a time are suppressed with all lanes busy.  A row's own store writes zeros everywhere except into the
+// queued groups, whose four bytes are written once, by the lane that takes the entry.
+constexpr int WQ_CAP = 128;  // at most 63 waiting + 64 new entries per group of four pixels
+
+
+struct WideArgs {
+    Plane src, gray, bin, dst;
+    u32* bits;
+    size_t bpw, bsw;
+    int w, h, strips_x, bands;
+    u32 nwaves;
+    int low, high, tiles_x, tiles_y;
+    u8* has_weak;
+    // threshold: "above" <=> gray + k >= 256 with k = 255 - t in 0 .. 255 (0: never)
+    u32 k7;    // (k & 0x7f) in every byte
+    u32 kb;    // 0x80808080 when k >= 128, else 0
+    u32 a4, b4, nz_a, nz_b;  // value above / below in every byte; 0xffff when that value is non-zero
+    ClearList clr;
+};
+
+// Q15 luma, scaled by two so that the gray value is byte 2 of the result: 2 * 3735 = 29 * 256 + 46,
+// 2 * 19235 = 150 * 256 + 70, 2 * 9798 = 76 * 256 + 140; `sh` = byte position of B inside `px` (0 or 1).
+__device__ __forceinline__ u32 luma2_at(u32 px, int sh)
+{
+    const u32 hi = __builtin_amdgcn_udot4(px, sh ? 0x4c961d00u : 0x004c961du, 0u, false);
+    const u32 lo = __builtin_amdgcn_udot4(px, sh ? 0x8c462e00u : 0x008c462eu, 32768u, false);
+    return (hi << 8) + lo;
+}
+
+// four bytes at any byte address (global memory is accessed in the unaligned mode, as by the loads of k_canny_stream)
+struct __attribute__((packed, aligned(4))) U1 { u32 x; };
+
+template <bool BGR_IN, int NP, int ROWS>
+// (16 pixels per lane need about 170 registers: three waves per SIMD are asked for, which costs a few spills
+// and measures faster than two waves)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 8 ? 3 : 4, 8))) void k_canny_wide(WideArgs A)
+{
+    constexpr int PX = 2 * NP, NQ = NP / 2, ND = PX / 4, NB = BGR_IN ? 3 * ND : ND, COLS = 64 * PX, NIT = ROWS + 4;
+    static_assert(NP == 4 || NP == 8, "8 or 16 pixels per lane");
+    static_assert(NIT % 3 == 0 && ROWS <= 125, "the row loop is unrolled by three; 7 bits of row in a queue entry");
+    __shared__ uint4 s_q[4][3][WQ_CAP];
+    // per wave, strip side (0 = left, 1 = right) and gray row of the band: what the column next to the strip
+    // contributes (.x = vertical sum | vertical difference << 16 and .y = magnitude | "the row's halo pixels equal
+    // their neighbour inside the strip" << 16; sum, difference and magnitude belong to the row before)
+    __shared__ uint2 s_h[4][2][NIT];
+    if (A.clr.n[0] | A.clr.n[1] | A.clr.n[2]) {  // (uniform) the first workgroup zeroes the scratch of the stages that follow
+        if (blockIdx.x == 0) {
+            for (int a = 0; a < 3; a++)
+                for (u32 i = threadIdx.x; i < A.clr.n[a]; i += 256) A.clr.p[a][i] = 0;
+        }
+    }
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 wid = xcd_contiguous_id(blockIdx.x, gridDim.x) * 4u + (u32)wv;
+    if (wid >= A.nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const int w = A.w, h = A.h;
+    const u32 t_ = wid / (u32)A.strips_x;
+    const int sx = (int)(wid - t_ * (u32)A.strips_x);
+    const int b = (int)(t_ / (u32)A.bands), band = (int)(t_ - (u32)b * (u32)A.bands);
+    const int X0 = sx * COLS;  // first column of the strip (wave-uniform)
+    const int x0 = X0 + PX * lane;
+    const int y0 = band * ROWS, y1 = min(y0 + ROWS, h);
+    // the image width is a multiple of PX (checked by the host): a lane lies inside the image or beyond it
+    const bool live = x0 < w;
+    const bool wave_edge = X0 + COLS > w;  // (uniform) the strip reaches beyond the image
+    const u8* const simg = A.src.p + (size_t)b * A.src.stride;
+    const u32 spitch = (u32)A.src.pitch;
+    const int xc = live ? x0 : w - PX;  // a lane beyond the image loads the row's last pixels and replicates the last one
+    const u32 xoff = (u32)xc * (BGR_IN ? 3u : 1u);
+    struct Raw {
+        u32 d[NB];
+    };
+    auto load_row = [&](int gy) -> Raw {
+        Raw r;
+        const u32 row = (u32)clampi(gy, 0, h - 1) * spitch;
+        const u8* p = simg + (size_t)(row + xoff);
+        if (NB % 4 == 0) {
+#pragma unroll
+            for (int k = 0; k < NB / 4; k++) {
+                const uint4 v = ((const uint4*)p)[k];
+                r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB / 2; k++) {
+                const uint2 v = ((const uint2*)p)[k];
+                r.d[2 * k] = v.x; r.d[2 * k + 1] = v.y;
+            }
+        }
+        return r;
+    };
+    // the first rows of the strip are on their way while the halo table is made
+    Raw buf[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) buf[k] = load_row(y0 - 2 + k);
+    // ---- the columns next to the strip, for all rows of the band at once: lane = row.  A lane reads the three
+    // pixels around the strip border of its row (left: columns X0 - 2, X0 - 1, X0; right: Xe - 1, Xe, Xe + 1 with
+    // Xe = the column behind the strip's last one inside the image; replicated at the image border), the rows
+    // above come from the lanes below, and the middle column's Sobel terms go to s_h.
+    {
+        constexpr int NPASS = (NIT + 61) / 62;
+        const int Xe = min(X0 + COLS, w);
+        // raw words of the six pixels of every pass first (all loads in flight together), then the arithmetic
+        u32 raw[NPASS][6];
+        int shf[6];
+        u32 coff[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int cc = clampi(k < 3 ? X0 - 2 + k : Xe - 4 + k, 0, w - 1);
+            const int o = BGR_IN ? max(3 * cc - 1, 0) : cc;  // (the 4 bytes read end inside the row's last pixel)
+            coff[k] = (u32)o;
+            shf[k] = BGR_IN ? 8 * (3 * cc - o) : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < NPASS; t++) {
+            const int j = 62 * t + lane - 2;  // gray row of the band this lane holds (rows j - 1, j - 2: the lanes below)
+            const u32 rowoff = (u32)clampi(y0 - 2 + j, 0, h - 1) * spitch;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (BGR_IN) raw[t][k] = (*(const U1*)(simg + (size_t)(rowoff + coff[k]))).x;
+                else raw[t][k] = simg[(size_t)(rowoff + coff[k])];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NPASS; t++) {
+            const int j = 62 * t + lane - 2;
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                u32 gC[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const u32 rw = raw[t][3 * side + k];
+                    gC[k] = BGR_IN ? (luma2_at(rw >> shf[3 * side + k], 0) >> 16) & 0xffu : rw;
+                }
+                const u32 pk = gC[0] | (gC[1] << 8) | (gC[2] << 16);
+                const u32 pB = (u32)__builtin_amdgcn_update_dpp(0, (int)pk, 0x138, 0xf, 0xf, false);  // row j - 1
+                const u32 pA = (u32)__builtin_amdgcn_update_dpp(0, (int)pB, 0x138, 0xf, 0xf, false);  // row j - 2
+                int vs[3], vd[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int a_ = (int)((pA >> (8 * k)) & 0xffu), b_ = (int)((pB >> (8 * k)) & 0xffu), c_ = (int)gC[k];
+                    vs[k] = a_ + 2 * b_ + c_;
+                    vd[k] = c_ - a_;
+                }
+                const int dx = vs[2] - vs[0], dy = vd[0] + 2 * vd[1] + vd[2];
+                // magnitude is 0 outside the image
+                const bool inside = side ? Xe < w : X0 > 0;
+                const u32 m = inside ? (u32)(abs(dx) + abs(dy)) : 0u;
+                const u32 same = (gC[0] == gC[1] && gC[1] == gC[2]) ? 1u : 0u;
+                if (lane >= 2 && j < NIT) s_h[wv][side][j] = make_uint2(((u32)vs[1] & 0xffffu) | ((u32)vd[1] << 16), m | (same << 16));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint2* const hrow = s_h[wv][lane == 63 ? 1 : 0];  // (lanes 1 .. 62 read the left side's entry and do not use it)
+    const bool isE = lane == 0 || lane == 63;
+
+    const u32 lane_mask = live ? 0xffffffffu : 0u;
+    u8* const dimg = A.dst.p + (size_t)b * A.dst.stride;
+    u8* const gimg = BGR_IN ? A.gray.p + (size_t)b * A.gray.stride : nullptr;
+    u8* const timg = BGR_IN && A.bin.p ? A.bin.p + (size_t)b * A.bin.stride : nullptr;
+    u8* const bimg = BGR_IN && A.bits ? (u8*)(A.bits + (size_t)b * A.bsw) : nullptr;
+    const u32 dpitch = (u32)A.dst.pitch, gpitch = BGR_IN ? (u32)A.gray.pitch : 0u, tpitch = timg ? (u32)A.bin.pitch : 0u;
+    u8* const weak_img = A.has_weak + (size_t)b * A.tiles_y * A.tiles_x;
+    uint4(*const q)[WQ_CAP] = s_q[wv];
+    u32 pending = 0;  // (uniform) entries on the stack
+    const u32 low2 = (u32)__builtin_amdgcn_readfirstlane(min(max(A.low, 0), 0x7fff) * 0x00010001);
+    const u32 high2 = (u32)__builtin_amdgcn_readfirstlane(min(max(A.high, 0), 0x7fff) * 0x00010001);
+    const u32 span2 = (u32)__builtin_amdgcn_readfirstlane((int)((255u - WEAK) * 0x00010001u));
+
+    // entries first .. first + count - 1 (count <= 64) leave the stack: lane i suppresses entry first + i
+    auto pop = [&](u32 first, u32 count) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((u32)lane < count) {
+            const uint4 e0 = q[0][first + lane], e1 = q[1][first + lane], e2 = q[2][first + lane];
+            const u32 info = e2.w;
+            const bool pz = (info & (1u << 16)) != 0, nz = (info & (1u << 17)) != 0;  // row above / below known to be zero
+            const u32 c01 = e0.x, c23 = e0.y, cO = e0.z;
+            const u32 p01 = pz ? 0u : e1.x, p23 = pz ? 0u : e1.y, pO = pz ? 0u : e1.z;
+            const u32 n01 = nz ? 0u : e2.x, n23 = nz ? 0u : e2.y, nO = nz ? 0u : e2.z;
+            // xO: column -1 in the high half, column 4 in the low half
+            const u32 cA = __builtin_amdgcn_alignbit(c01, cO, 16), cB = __builtin_amdgcn_alignbit(c23, c01, 16),
+                      cC = __builtin_amdgcn_alignbit(cO, c23, 16);
+            const u32 pA = __builtin_amdgcn_alignbit(p01, pO, 16), pB = __builtin_amdgcn_alignbit(p23, p01, 16),
+                      pC = __builtin_amdgcn_alignbit(pO, p23, 16);
+            const u32 nA = __builtin_amdgcn_alignbit(n01, nO, 16), nB = __builtin_amdgcn_alignbit(n23, n01, 16),
+                      nC = __builtin_amdgcn_alignbit(nO, n23, 16);
+            // |dx| with the sign of dx ^ dy in bit 15 of each half; |dy| = magnitude - |dx|
+            const u32 ax01 = e0.w & 0x7fff7fffu, ax23 = e1.w & 0x7fff7fffu;
+            const u32 ay01 = as_u32(as_s2(c01) - as_s2(ax01)), ay23 = as_u32(as_s2(c23) - as_s2(ax23));
+            const u32 k01 = nms_pair(c01, ax01, ay01, e0.w, cA, cB, pA, p01, pB, nA, n01, nB, low2, high2, span2);
+            const u32 k23 = nms_pair(c23, ax23, ay23, e1.w, cB, cC, pB, p23, pC, nB, n23, nC, low2, high2, span2);
+            const u32 codes = __builtin_amdgcn_perm(k23, k01, 0x06040200u);
+            const u32 ey = (u32)y0 + (info & 0x7fu), ex = (u32)X0 + (u32)PX * ((info >> 8) & 0x3fu) + 4u * ((info >> 18) & 3u);
+            *(u32*)(dimg + (size_t)(ey * dpitch + ex)) = codes;
+            if (codes & ~(codes >> 7) & 0x01010101u) weak_img[(ey / TH) * (u32)A.tiles_x + ex / TW] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // rolling state: gray rows gy-2 (a), gy-1 (bq) as 16-bit pairs; magnitude rows gy-3 (mp), gy-2 (mc) with the
+    // neighbouring lanes' columns; |dx| (sign of dx ^ dy in bit 15) of row gy-2
+    u32 a[NP], bq[NP];
+    u32 mp[NP], mc[NP], mpL = 0, mpR = 0, mcL = 0, mcR = 0, axc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) a[p] = bq[p] = mp[p] = mc[p] = axc[p] = 0;
+    int flat_run = 0;  // consecutive flat rows of value flat_val ending at the newest row
+    u32 flat_val = 0;
+    bool mp_zero = true, mc_zero = true;
+    const u32 lane_info = (u32)lane << 8;
+
+#pragma unroll 3
+    for (int it = 0; it < NIT; it++) {
+        const int gy = y0 - 2 + it;
+        // (uniform) past the band's last row nothing is left to do; the trip count stays fixed so that the loop can be
+        // unrolled by three, the period of the rolling registers
+        if (gy - 2 < y1) {
+        const Raw cur = buf[it % 3];
+        buf[it % 3] = load_row(gy + 3);
+        const uint2 hv = hrow[it];
+        const bool own_row = it >= 2 && gy < y1;  // (uniform) a row of this band: its planes are written
+        // ---- the lane's pixels of gray row gy as bytes (g) and as 16-bit pairs (c)
+        u32 g[ND], c[NP];
+        bool flat_c;
+        u32 val_c;
+        {
+            const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)cur.d[0]);
+            u32 diff = d0 ^ __builtin_rotateleft32(d0, 8);
+#pragma unroll
+            for (int k = 0; k < NB; k++) diff |= cur.d[k] ^ d0;
+            if (isE) diff |= ~hv.y & 0x10000u;  // the pixels beside the strip differ from it
+            flat_c = __all(diff == 0);
+            val_c = d0 & 0xffu;  // (B = G = R = v gives gray v)
+        }
+        if (flat_c) {
+            const u32 v4 = val_c * 0x01010101u, v2 = val_c * 0x00010001u;
+#pragma unroll
+            for (int k = 0; k < ND; k++) g[k] = v4;
+#pragma unroll
+            for (int p = 0; p < NP; p++) c[p] = v2;
+        } else {
+            if (BGR_IN) {
+                u32 t2[PX];
+#pragma unroll
+                for (int k = 0; k < PX; k++) {
+                    const int qd = (3 * k) >> 2, sb = (3 * k) & 3;
+                    // pixel k starts at byte sb of dword qd: sb = 0: as is; 1: coefficients one byte up; 2, 3: across two dwords
+                    if (sb == 0) t2[k] = luma2_at(cur.d[qd], 0);
+                    else if (sb == 1) t2[k] = luma2_at(cur.d[qd], 1);
+                    else t2[k] = luma2_at(__builtin_amdgcn_alignbyte(cur.d[qd + 1], cur.d[qd], (u32)sb), 0);
+                }
+#pragma unroll
+                for (int p = 0; p < NP; p++) c[p] = __builtin_amdgcn_perm(t2[2 * p + 1], t2[2 * p], 0x0c060c02u);
+#pragma unroll
+                for (int k = 0; k < ND; k++) g[k] = __builtin_amdgcn_perm(c[2 * k + 1], c[2 * k], 0x06040200u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < ND; k++) g[k] = cur.d[k];
+#pragma unroll
+                for (int p = 0; p < NP; p++) c[p] = __builtin_amdgcn_perm(0u, g[p >> 1], (p & 1) ? PAIR_SEL(2, 3) : PAIR_SEL(0, 1));
+            }
+            if (wave_edge) {  // lanes beyond the right image border: the last pixel of the row, replicated
+                const u32 rep4 = (g[ND - 1] >> 24) * 0x01010101u, rep2 = (g[ND - 1] >> 24) * 0x00010001u;
+#pragma unroll
+                for (int k = 0; k < ND; k++) g[k] = live ? g[k] : rep4;
+#pragma unroll
+                for (int p = 0; p < NP; p++) c[p] = live ? c[p] : rep2;
+            }
+        }
+        // ---- gray, thresholded plane and bit plane of the band's own rows
+        if (BGR_IN && own_row) {
+            u32 tb[ND], above = 0;  // bit k of `above`: pixel k is above the threshold
+            if (timg) {
+#pragma unroll
+                for (int k = 0; k < ND; k++) {
+                    // carry out of every byte of g + k: into bit 7 of L from the low seven bits, then the majority with the top bits
+                    const u32 L = (g[k] & 0x7f7f7f7fu) + A.k7;
+                    const u32 R = (L & (g[k] | A.kb)) | (g[k] & A.kb);
+                    const u32 b1 = (R >> 7) & 0x01010101u;  // 1 in every byte above the threshold
+                    const u32 m = (b1 << 8) - b1;           // 0xff in those bytes
+                    tb[k] = (m & A.a4) | (~m & A.b4);
+                    above |= __builtin_amdgcn_udot4(b1, 0x08040201u, 0u, false) << (4 * k);
+                }
+            }
+            if (live) {
+                u8* const gd = gimg + (size_t)((u32)gy * gpitch + (u32)x0);
+                if (ND == 4) *(uint4*)gd = make_uint4(g[0], g[1], g[2], g[ND - 1]);
+                else *(uint2*)gd = make_uint2(g[0], g[1]);
+                if (timg) {
+                    u8* const td = timg + (size_t)((u32)gy * tpitch + (u32)x0);
+                    if (ND == 4) *(uint4*)td = make_uint4(tb[0], tb[1], tb[2], tb[ND - 1]);
+                    else *(uint2*)td = make_uint2(tb[0], tb[1]);
+                }
+            }
+            if (bimg) {
+                // Byte or halfword stores from all 64 lanes are slow: the bits of 16 (PX = 8) or 8 (PX = 16) neighbouring
+                // lanes are gathered into one lane by lane moves inside each row of 16 lanes, and that lane stores 16 bytes,
+                // so that the wave's 64 or 128 bytes of the bit-plane row leave in one instruction of 4 or 8 lanes.
+                // (lanes beyond the image contribute the zero bits of the row's last words)
+                const u32 mybits = ((above & A.nz_a) | (~above & A.nz_b)) & (live ? (PX == 16 ? 0xffffu : 0xffu) : 0u);
+                u32 w0;
+                if (PX == 16) {
+                    w0 = mybits | ((u32)__builtin_amdgcn_update_dpp(0, (int)mybits, 0x101, 0xf, 0xf, true) << 16);  // lanes 2k: bits of 2k, 2k+1
+                } else {
+                    const u32 h0 = mybits | ((u32)__builtin_amdgcn_update_dpp(0, (int)mybits, 0x101, 0xf, 0xf, true) << 8);
+                    w0 = h0 | ((u32)__builtin_amdgcn_update_dpp(0, (int)h0, 0x102, 0xf, 0xf, true) << 16);          // lanes 4k: bits of 4k .. 4k+3
+                }
+                constexpr int S1 = PX == 16 ? 2 : 4;  // lanes per dword
+                const u32 w1 = (u32)__builtin_amdgcn_update_dpp(0, (int)w0, 0x100 + S1, 0xf, 0xf, true);
+                const u32 w2 = (u32)__builtin_amdgcn_update_dpp(0, (int)w0, 0x100 + 2 * S1, 0xf, 0xf, true);
+                const u32 w3 = (u32)__builtin_amdgcn_update_dpp(0, (int)w1, 0x100 + 2 * S1, 0xf, 0xf, true);
+                if ((lane & (4 * S1 - 1)) == 0)
+                    *(uint4*)(bimg + (size_t)gy * (A.bpw * 4) + (size_t)(x0 >> 3)) = make_uint4(w0, w1, w2, w3);
+            }
+        }
+        // ---- flat rows: three equal ones in a row have zero gradients
+        flat_run = flat_c ? (val_c == flat_val && flat_run > 0 ? flat_run + 1 : 1) : 0;
+        flat_val = val_c;
+        const bool mn_zero = it < 2 || flat_run >= 3 || gy - 1 < 0 || gy - 1 >= h;
+        u32 mn[NP], mnL, mnR, axn[NP];
+        if (mn_zero) {
+            // known to be zero: the flag stands for the values, the registers are only declared written
+#pragma unroll
+            for (int p = 0; p < NP; p++) asm("" : "=v"(mn[p]), "=v"(axn[p]));
+            asm("" : "=v"(mnL), "=v"(mnR));
+        } else {
+            // ---- gradients and magnitude of row gy-1 (gray rows gy-2 = a, gy-1 = bq, gy = c)
+            u32 vs[NP], vd[NP];
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                vs[p] = as_u32(as_s2(a[p]) + as_s2(bq[p]) + as_s2(bq[p]) + as_s2(c[p]));
+                vd[p] = as_u32(as_s2(c[p]) - as_s2(a[p]));
+            }
+            // the column beside the strip (lanes 0 and 63), in both halves of a word
+            const u32 vsH = __builtin_amdgcn_perm(0u, hv.x, 0x01000100u), vdH = __builtin_amdgcn_perm(0u, hv.x, 0x03020302u);
+            const u32 mH = __builtin_amdgcn_perm(0u, hv.y, 0x01000100u);
+            // columns -1 (high half of xL; lane 0: from the table) and PX (low half of xR; lane 63: from the table)
+            const u32 vsL = (u32)__builtin_amdgcn_update_dpp((int)vsH, (int)vs[NP - 1], 0x138, 0xf, 0xf, false);
+            const u32 vsR = (u32)__builtin_amdgcn_update_dpp((int)vsH, (int)vs[0], 0x130, 0xf, 0xf, false);
+            const u32 vdL = (u32)__builtin_amdgcn_update_dpp((int)vdH, (int)vd[NP - 1], 0x138, 0xf, 0xf, false);
+            const u32 vdR = (u32)__builtin_amdgcn_update_dpp((int)vdH, (int)vd[0], 0x130, 0xf, 0xf, false);
+            // odd pairs: o[k] = columns 2k-1, 2k
+            u32 os[NP + 1], od[NP + 1];
+            os[0] = __builtin_amdgcn_alignbit(vs[0], vsL, 16);
+            od[0] = __builtin_amdgcn_alignbit(vd[0], vdL, 16);
+#pragma unroll
+            for (int k = 1; k < NP; k++) {
+                os[k] = __builtin_amdgcn_alignbit(vs[k], vs[k - 1], 16);
+                od[k] = __builtin_amdgcn_alignbit(vd[k], vd[k - 1], 16);
+            }
+            os[NP] = __builtin_amdgcn_alignbit(vsR, vs[NP - 1], 16);
+            od[NP] = __builtin_amdgcn_alignbit(vdR, vd[NP - 1], 16);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const s2 dx = as_s2(os[p + 1]) - as_s2(os[p]);
+                const s2 dy = as_s2(od[p]) + as_s2(od[p + 1]) + as_s2(vd[p]) + as_s2(vd[p]);
+                const s2 adx = __builtin_elementwise_abs(dx), ady = __builtin_elementwise_abs(dy);
+                mn[p] = as_u32(adx + ady);
+                axn[p] = as_u32(adx) | ((as_u32(dx) ^ as_u32(dy)) & 0x80008000u);
+            }
+            if (wave_edge) {  // magnitude is 0 outside the image
+#pragma unroll
+                for (int p = 0; p < NP; p++) mn[p] &= lane_mask;
+            }
+            mnL = (u32)__builtin_amdgcn_update_dpp((int)mH, (int)mn[NP - 1], 0x138, 0xf, 0xf, false);
+            mnR = (u32)__builtin_amdgcn_update_dpp((int)mH, (int)mn[0], 0x130, 0xf, 0xf, false);
+        }
+        // ---- row ry = gy - 2: candidates go onto the stack, everything else is written as zero
+        const int ry = gy - 2;
+        if (it >= 4) {  // (ry < y1 by the loop's exit test)
+            bool cq[NQ];
+            bool anyc = false;
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                cq[k] = !mc_zero && (pk_sub_sat_u16(mc[2 * k], low2) | pk_sub_sat_u16(mc[2 * k + 1], low2)) != 0;
+                anyc = anyc || cq[k];
+            }
+            u8* const ed = dimg + (size_t)((u32)ry * dpitch + (u32)x0);
+            if (!mc_zero && __any(anyc)) {
+                const u32 row_info = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(it - 4) | (mp_zero ? 1u << 16 : 0u) | (mn_zero ? 1u << 17 : 0u)));
+#pragma unroll
+                for (int k = 0; k < NQ; k++) {
+                    const unsigned long long cmask = __ballot(cq[k]);
+                    if (cmask == 0) continue;  // (uniform)
+                    if (cq[k]) {
+                        const u32 pos = pending + __builtin_amdgcn_mbcnt_hi((u32)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)cmask, 0u));
+                        // columns -1 (high half) and 4 (low half) of the group in one word, per row
+                        const u32 cl = k == 0 ? mcL : mc[2 * k - 1], cr = k == NQ - 1 ? mcR : mc[2 * k + 2 < NP ? 2 * k + 2 : 0];
+                        const u32 pl = k == 0 ? mpL : mp[2 * k - 1], pr = k == NQ - 1 ? mpR : mp[2 * k + 2 < NP ? 2 * k + 2 : 0];
+                        const u32 nl = k == 0 ? mnL : mn[2 * k - 1], nr = k == NQ - 1 ? mnR : mn[2 * k + 2 < NP ? 2 * k + 2 : 0];
+                        q[0][pos] = make_uint4(mc[2 * k], mc[2 * k + 1], __builtin_amdgcn_perm(cl, cr, 0x07060100u), axc[2 * k]);
+                        q[1][pos] = make_uint4(mp[2 * k], mp[2 * k + 1], __builtin_amdgcn_perm(pl, pr, 0x07060100u), axc[2 * k + 1]);
+                        q[2][pos] = make_uint4(mn[2 * k], mn[2 * k + 1], __builtin_amdgcn_perm(nl, nr, 0x07060100u),
+                                               lane_info | row_info | ((u32)k << 18));
+                    }
+                    pending += (u32)__popcll(cmask);
+                    if (pending >= 64) {
+                        pop(pending - 64, 64);
+                        pending -= 64;
+                    }
+                }
+                if (live) {
+                    if (!anyc) {
+                        if (ND == 4) *(uint4*)ed = make_uint4(0, 0, 0, 0);
+                        else *(uint2*)ed = make_uint2(0, 0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NQ; k++)
+                            if (!cq[k]) *(u32*)(ed + 4 * k) = 0;
+                    }
+                }
+            } else if (live) {
+                if (ND == 4) *(uint4*)ed = make_uint4(0, 0, 0, 0);
+                else *(uint2*)ed = make_uint2(0, 0);
+            }
+        }
+        // ---- roll the window
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            a[p] = bq[p]; bq[p] = c[p];
+            mp[p] = mc[p]; mc[p] = mn[p];
+            axc[p] = axn[p];
+        }
+        mpL = mcL; mpR = mcR; mcL = mnL; mcR = mnR;
+        mp_zero = mc_zero; mc_zero = mn_zero;
+        }
+    }
+    if (pending != 0) pop(0, pending);
+}
+
 constexpr int HT_THREADS = 512;      // 8 waves per workgroup (16 when there are few workgroups)
 constexpr int HT_MAX_TILES = 4096;   // tiles per region (one workgroup)
 
@@ -939,6 +1383,89 @@ static void launch_hyst_final(Plane dst, int w, int h, int tiles_x, int tiles_y,
 
 }  // namespace
 
+// ---- launch of the wide kernel -------------------------------------------------------------------------
+// np = 16-bit pixel pairs per lane (4 or 8).  The kernel keeps 32-bit offsets within an image and whole pixel
+// groups of a lane inside a row.
+bool canny_wide_fits(int w, int h, size_t src_pitch, size_t dst_pitch, size_t gray_pitch, size_t bin_pitch, int np)
+{
+    if (np != 4 && np != 8) return false;
+    if (w < 2 * np || w % (2 * np) != 0 || h < 1 || w > 65535 || h > 65535) return false;  // whole pixel groups of a lane
+    const unsigned long long lim = 0xffffffffull - 64;
+    return (unsigned long long)h * src_pitch < lim && (unsigned long long)h * dst_pitch < lim &&
+           (unsigned long long)h * gray_pitch < lim && (unsigned long long)h * bin_pitch < lim;
+}
+
+constexpr int WIDE_ROWS = 125, WIDE_ROWS_SHORT = 14;
+
+// Pixel pairs per lane the wide kernel would use for this launch: 0 = not used.  Option canny_wide: 0 = never,
+// 4 / 8 = always (where it fits), -1 = for launches that fill the chip with bands of WIDE_ROWS rows.
+int canny_wide_np(int w, int h, int batch)
+{
+    const int opt = option_canny_wide();
+    if (opt == 0) return 0;
+    if (opt == 4 || opt == 8) return opt;
+    const int np = 8;
+    const long long waves = (long long)cdiv(w, 128 * np) * cdiv(h, WIDE_ROWS) * batch;
+    return waves >= 4096 ? np : 0;
+}
+
+int launch_canny_wide(bool bgr_in, int np, Plane src, Plane gray, Plane bin, u32* bits, size_t bpw, size_t bsw, Plane dst, int w,
+                      int h, int batch, int ithresh, int maxval, int inv, int low, int high, void* canny_ws, ClearList clr,
+                      hipStream_t st)
+{
+    const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+    IPA_REQUIRE(canny_wide_fits(w, h, src.pitch, dst.pitch, bgr_in ? gray.pitch : 0, bgr_in && bin.p ? bin.pitch : 0, np),
+                IPA_ERR_ARG, "Canny (wide kernel): image shape not supported");
+    for (int b0 = 0; b0 < batch; b0 += 32768) {
+        const int nb = batch - b0 < 32768 ? batch - b0 : 32768;
+        WideArgs A;
+        A.src = src; A.gray = gray; A.bin = bin; A.dst = dst;
+        A.src.p += (size_t)b0 * src.stride;
+        A.dst.p += (size_t)b0 * dst.stride;
+        if (A.gray.p) A.gray.p += (size_t)b0 * gray.stride;
+        if (A.bin.p) A.bin.p += (size_t)b0 * bin.stride;
+        A.bits = bits ? bits + (size_t)b0 * bsw : nullptr;
+        A.bpw = bpw; A.bsw = bsw;
+        A.w = w; A.h = h;
+        A.strips_x = cdiv(w, 128 * np);
+        const bool short_bands = (long long)A.strips_x * cdiv(h, WIDE_ROWS) * nb < 2048;
+        const int rows = short_bands ? WIDE_ROWS_SHORT : WIDE_ROWS;
+        A.bands = cdiv(h, rows);
+        const long long nwaves = (long long)A.strips_x * A.bands * nb;
+        IPA_REQUIRE(nwaves < 0x7fffffffLL, IPA_ERR_ARG, "Canny (wide kernel): too many strips");
+        A.nwaves = (u32)nwaves;
+        A.low = low; A.high = high; A.tiles_x = tiles_x; A.tiles_y = tiles_y;
+        A.has_weak = (u8*)canny_ws + (size_t)b0 * tiles_x * tiles_y;
+        // "above" <=> gray > t <=> gray + (255 - t) >= 256; t < 0: every pixel is above
+        u32 va = inv ? 0u : (u32)maxval, vb = inv ? (u32)maxval : 0u;
+        int k = 255 - (ithresh > 255 ? 255 : ithresh);
+        if (ithresh < 0) {
+            const u32 tmp = va;
+            va = vb;
+            vb = tmp;
+            k = 0;
+        }
+        A.k7 = (u32)(k & 0x7f) * 0x01010101u;
+        A.kb = k >= 128 ? 0x80808080u : 0u;
+        A.a4 = va * 0x01010101u; A.b4 = vb * 0x01010101u;
+        A.nz_a = va ? 0xffffu : 0u; A.nz_b = vb ? 0xffffu : 0u;
+        A.clr = clr;
+        const dim3 grid((unsigned)((nwaves + 3) / 4));
+#define IPA_WIDE(BGRV, NPV, ROWSV) hipLaunchKernelGGL((k_canny_wide<BGRV, NPV, ROWSV>), grid, dim3(256), 0, st, A)
+        if (bgr_in) {
+            if (np == 8) { if (short_bands) IPA_WIDE(true, 8, WIDE_ROWS_SHORT); else IPA_WIDE(true, 8, WIDE_ROWS); }
+            else { if (short_bands) IPA_WIDE(true, 4, WIDE_ROWS_SHORT); else IPA_WIDE(true, 4, WIDE_ROWS); }
+        } else {
+            if (np == 8) { if (short_bands) IPA_WIDE(false, 8, WIDE_ROWS_SHORT); else IPA_WIDE(false, 8, WIDE_ROWS); }
+            else { if (short_bands) IPA_WIDE(false, 4, WIDE_ROWS_SHORT); else IPA_WIDE(false, 4, WIDE_ROWS); }
+        }
+#undef IPA_WIDE
+        IPA_LAUNCH_CHECK();
+        clr.n[0] = clr.n[1] = clr.n[2] = 0;  // (only the first launch clears)
+    }
+    return IPA_OK;
+}
+
 size_t canny_ws_bytes(int w, int h, int batch)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
@@ -960,7 +1487,7 @@ void canny_flag_area(int w, int h, int batch, void* ws, u32** p, u32* dwords)
 }
 
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
-              PointSink sink, hipStream_t st, bool flags_cleared)
+              PointSink sink, hipStream_t st, bool flags_cleared, bool nms_done)
 {
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     const long long ntiles_ll = (long long)tiles_x * tiles_y * batch;
@@ -994,7 +1521,17 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         const char* e = getenv("IPA_CANNY_MODE");
         mode = e ? atoi(e) : 1;
     }
-    {
+    // nms_done: the fused BGR kernel has already written the codes and the tile flags of this batch
+    const int wide_np = nms_done || sink.pts || mode != 1 ? 0 : canny_wide_np(w, h, batch);
+    if (nms_done) {
+    } else if (wide_np && canny_wide_fits(w, h, src.pitch, dst.pitch, 0, 0, wide_np)) {
+        ProfScope ps(PROF_CANNY_NMS, st);
+        if (!flags_cleared) IPA_HIP(hipMemsetAsync(W.has_weak, 0, (two_step ? 2 : 1) * align_up(ntiles, 256), st));
+        const ClearList none = {{nullptr, nullptr, nullptr}, {0, 0, 0}};
+        const int rc = launch_canny_wide(false, wide_np, src, mkplane(nullptr, 0, 0), mkplane(nullptr, 0, 0), nullptr, 0, 0, dst, w, h,
+                                         batch, 0, 0, 0, low, high, W.has_weak, none, st);
+        if (rc) return rc;
+    } else {
         ProfScope ps(PROF_CANNY_NMS, st);
         // the streaming kernel reads whole 32-bit words inside a row and uses 32-bit offsets within an image
         const bool stream_ok = w >= 4 && (unsigned long long)h * src.pitch < 0xffffffffull && (unsigned long long)h * dst.pitch < 0xffffffffull;

@@ -5,6 +5,7 @@
 // Every kernel moves 16 pixels per lane with 16-byte accesses; a wave64 touches
 // 1 KiB (gray) or 3 KiB (BGR) of contiguous memory per row segment.
 #include "common.hpp"
+#include "gray_core.hpp"
 
 #include <float.h>
 
@@ -32,7 +33,7 @@ __device__ __forceinline__ u32 luma_dot(u32 px)
 template <bool THRESH, bool PACK>
 __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* __restrict__ bits,
                                                   size_t bpw, size_t bsw, int w, int h, int cpr, int ithresh,
-                                                  u32 v_above, u32 v_below, ClearList clr)
+                                                  u32 v_above, u32 v_below, u32 k7, u32 kb, ClearList clr)
 {
     if (clr.n[0] | clr.n[1] | clr.n[2]) {  // (wave-uniform) the first workgroup zeroes the scratch of the stages that follow
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
@@ -75,25 +76,12 @@ __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane b
             if (full) {
                 const u32 d[13] = {in[i][0].x, in[i][0].y, in[i][0].z, in[i][0].w, in[i][1].x, in[i][1].y, in[i][1].z,
                                    in[i][1].w, in[i][2].x, in[i][2].y, in[i][2].z, in[i][2].w, 0u};
-                u32 g[4] = {0, 0, 0, 0};
-                u32 above = 0;  // bit k: pixel k is above the threshold
-#pragma unroll
-                for (int k = 15; k >= 0; k--) {
-                    const int q = (3 * k) >> 2, sh = (3 * k) & 3;
-                    const u32 px = sh ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh) : d[q];
-                    const u32 v = luma_dot(px);
-                    g[k >> 2] |= v << (8 * (k & 3));
-                    if (THRESH) above = (above << 1) | ((u32)(ithresh - (int)v) >> 31);
-                }
+                u32 g[4];
+                gray16(d, g);
                 *(uint4*)gd = make_uint4(g[0], g[1], g[2], g[3]);
                 if (THRESH) {
                     u32 t[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const u32 sp = (((above >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;  // bit -> byte
-                        const u32 m = (sp << 8) - sp;                                               // 0x00 / 0xff
-                        t[q] = (m & a4) | (~m & b4);
-                    }
+                    const u32 above = thresh16(g, t, k7, kb, a4, b4);  // bit k: pixel k is above the threshold
                     *(uint4*)(timg + (size_t)y * bin.pitch + doff) = make_uint4(t[0], t[1], t[2], t[3]);
                     if (PACK) mybits = (above & nz_a) | (~above & nz_b);
                 }
@@ -138,15 +126,10 @@ __global__ __launch_bounds__(256) void k_bgr2gray(Plane bgr, Plane gray, Plane b
 }
 
 // The same conversion with ONE 16-pixel chunk per lane and consecutive lanes on consecutive chunks of the image in
-// row-major order (a wave = 1024 consecutive pixels, wrapping over row ends): measured 7 % faster than the
-// 4-row shape above on this traffic pattern (scripts/micro/gray_shapes.hip: 5.6 against 5.2 TB/s).  A lane stores
-// its 16 bit-plane bits as two bytes, a wave thereby one whole 128-byte line of a bit-plane row.
-// row = chunk / cpr by multiplication: chunk < 2^28, div_m = floor(2^div_k / cpr) + 1, div_k = 28 + bits(cpr).
+// row-major order (gray_flat_chunk in gray_core.hpp): measured 7 % faster than the 4-row shape above on this traffic
+// pattern (scripts/micro/gray_shapes.hip: 5.6 against 5.2 TB/s).
 template <bool THRESH, bool PACK>
-__global__ __launch_bounds__(256) void k_bgr2gray_flat(Plane bgr, Plane gray, Plane bin, u32* __restrict__ bits,
-                                                       size_t bpw, size_t bsw, int w, int h, int cpr, u32 nchunks,
-                                                       u32 div_m, int div_k, int ithresh, u32 v_above, u32 v_below,
-                                                       ClearList clr)
+__global__ __launch_bounds__(256) void k_bgr2gray_flat(GrayArgs G, ClearList clr)
 {
     if (clr.n[0] | clr.n[1] | clr.n[2]) {  // (wave-uniform) the first workgroup zeroes the scratch of the stages that follow
         if (blockIdx.x == 0 && blockIdx.z == 0) {
@@ -155,58 +138,8 @@ __global__ __launch_bounds__(256) void k_bgr2gray_flat(Plane bgr, Plane gray, Pl
         }
     }
     const u32 ci = blockIdx.x * 256u + threadIdx.x;
-    if (ci >= nchunks) return;
-    const int b = blockIdx.z;
-    const u32 y = (u32)(((unsigned long long)ci * div_m) >> div_k);
-    const int cx = (int)(ci - y * (u32)cpr);
-    const bool live = cx * 16 < w;
-    const bool full = cx * 16 + 16 <= w;
-    const u8* const srow = bgr.p + (size_t)b * bgr.stride + (size_t)y * bgr.pitch + (size_t)cx * 48u;
-    u8* const gd = gray.p + (size_t)b * gray.stride + (size_t)y * gray.pitch + (size_t)cx * 16u;
-    u8* const td = THRESH ? bin.p + (size_t)b * bin.stride + (size_t)y * bin.pitch + (size_t)cx * 16u : nullptr;
-    const u32 a4 = v_above * 0x01010101u, b4 = v_below * 0x01010101u;
-    const u32 nz_a = v_above ? 0xffffu : 0u, nz_b = v_below ? 0xffffu : 0u;
-    u32 mybits = 0;
-    if (live && full) {
-        const uint4* s4 = (const uint4*)srow;
-        const uint4 i0 = s4[0], i1 = s4[1], i2 = s4[2];
-        const u32 d[13] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w, 0u};
-        u32 g[4] = {0, 0, 0, 0};
-        u32 above = 0;  // bit k: pixel k is above the threshold
-#pragma unroll
-        for (int k = 15; k >= 0; k--) {
-            const int q = (3 * k) >> 2, sh = (3 * k) & 3;
-            const u32 px = sh ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh) : d[q];
-            const u32 v = luma_dot(px);
-            g[k >> 2] |= v << (8 * (k & 3));
-            if (THRESH) above = (above << 1) | ((u32)(ithresh - (int)v) >> 31);
-        }
-        *(uint4*)gd = make_uint4(g[0], g[1], g[2], g[3]);
-        if (THRESH) {
-            u32 t[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32 sp = (((above >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;  // bit -> byte
-                const u32 m = (sp << 8) - sp;                                               // 0x00 / 0xff
-                t[q] = (m & a4) | (~m & b4);
-            }
-            *(uint4*)td = make_uint4(t[0], t[1], t[2], t[3]);
-            if (PACK) mybits = (above & nz_a) | (~above & nz_b);
-        }
-    } else if (live) {
-        const int n = w - cx * 16;
-        for (int k = 0; k < n; k++) {
-            const u32 v = luma(srow[3 * k], srow[3 * k + 1], srow[3 * k + 2]);
-            gd[k] = (u8)v;
-            if (THRESH) {
-                const bool above = (int)v > ithresh;
-                td[k] = (u8)(above ? v_above : v_below);
-                if (PACK) mybits |= (u32)((above ? v_above : v_below) != 0u) << k;
-            }
-        }
-    }
-    // (cpr is even: the chunk behind the last one of an odd row writes the zero half of the last word)
-    if (PACK) *(unsigned short*)((u8*)(bits + (size_t)b * bsw + (size_t)y * bpw) + (size_t)cx * 2u) = (unsigned short)mybits;
+    if (ci >= G.nchunks) return;
+    gray_flat_chunk<THRESH, PACK>(G, (int)blockIdx.z, ci);
 }
 
 // gray -> BGR (replicate) : 16 px per lane, 16 B in, 48 B out.
@@ -403,7 +336,11 @@ int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, siz
     int cpr = cdiv(w, 16);
     cpr += cpr & 1;
     if (cpr == 0 || h == 0 || batch == 0) return IPA_OK;
-    u32 va = inv ? 0u : (u32)maxval, vb = inv ? (u32)maxval : 0u;
+    // normalised so that "above" means gray > ithresh with ithresh in 0 .. 255 (a negative threshold, every pixel
+    // above, becomes "never above" with the two values swapped)
+    const ThreshK tk = thresh_consts(ithresh, inv ? 0u : (u32)maxval, inv ? (u32)maxval : 0u);
+    const u32 va = tk.va, vb = tk.vb, k7 = tk.k7, kb = tk.kb;
+    if (ithresh < 0 || ithresh > 255) ithresh = 255;
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         Plane sb = bgr, gb = gray, tb = bin;
@@ -417,34 +354,41 @@ int launch_bgr2gray(Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, siz
             const char* e = getenv("IPA_GRAY_FLAT");
             flat = e ? atoi(e) : 1;
         }
-        if (flat && (unsigned long long)cpr * h < (1ull << 28)) {
-            const u32 nchunks = (u32)cpr * (u32)h;
-            int lb = 0;
-            while ((1u << lb) <= (u32)cpr) lb++;  // cpr < 2^lb
-            const int div_k = 28 + lb;
-            const u32 div_m = (u32)((1ull << div_k) / (u32)cpr) + 1u;
-            const dim3 fgrid((nchunks + 255u) / 256u, 1, (unsigned)nb);
-            if (bin.p && bits)
-                hipLaunchKernelGGL((k_bgr2gray_flat<true, true>), fgrid, dim3(256), 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, nchunks, div_m, div_k, ithresh, va, vb, clr);
-            else if (bin.p)
-                hipLaunchKernelGGL((k_bgr2gray_flat<true, false>), fgrid, dim3(256), 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, nchunks, div_m, div_k, ithresh, va, vb, clr);
-            else
-                hipLaunchKernelGGL((k_bgr2gray_flat<false, false>), fgrid, dim3(256), 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, nchunks, div_m, div_k, ithresh, va, vb, clr);
+        GrayArgs G;
+        if (flat && gray_args_make(&G, sb, gb, tb, bb, bpw, bsw, w, h, ithresh, va, vb, k7, kb)) {
+            const dim3 fgrid((G.nchunks + 255u) / 256u, 1, (unsigned)nb);
+            if (bin.p && bits) hipLaunchKernelGGL((k_bgr2gray_flat<true, true>), fgrid, dim3(256), 0, st, G, clr);
+            else if (bin.p) hipLaunchKernelGGL((k_bgr2gray_flat<true, false>), fgrid, dim3(256), 0, st, G, clr);
+            else hipLaunchKernelGGL((k_bgr2gray_flat<false, false>), fgrid, dim3(256), 0, st, G, clr);
             IPA_LAUNCH_CHECK();
             clr.n[0] = clr.n[1] = clr.n[2] = 0;  // (only the first launch clears)
             continue;
         }
         // the bit plane holds "pixel is non-zero in the thresholded plane"
         if (bin.p && bits)
-            hipLaunchKernelGGL((k_bgr2gray<true, true>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
+            hipLaunchKernelGGL((k_bgr2gray<true, true>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, k7, kb, clr);
         else if (bin.p)
-            hipLaunchKernelGGL((k_bgr2gray<true, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
+            hipLaunchKernelGGL((k_bgr2gray<true, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, k7, kb, clr);
         else
-            hipLaunchKernelGGL((k_bgr2gray<false, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, clr);
+            hipLaunchKernelGGL((k_bgr2gray<false, false>), grid, block, 0, st, sb, gb, tb, bb, bpw, bsw, w, h, cpr, ithresh, va, vb, k7, kb, clr);
         IPA_LAUNCH_CHECK();
         clr.n[0] = clr.n[1] = clr.n[2] = 0;  // (only the first launch clears)
     }
     return IPA_OK;
+}
+
+bool gray_job_make(GrayJob* J, Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch,
+                   int ithresh, int maxval, int inv)
+{
+    if (batch <= 0 || !bin.p || !bits) return false;
+    const ThreshK tk = thresh_consts(ithresh, inv ? 0u : (u32)maxval, inv ? (u32)maxval : 0u);
+    if (ithresh < 0 || ithresh > 255) ithresh = 255;
+    if (!gray_args_make(&J->G, bgr, gray, bin, bits, bpw, bsw, w, h, ithresh, tk.va, tk.vb, tk.k7, tk.kb)) return false;
+    J->units_per_image = (J->G.nchunks + 63u) / 64u;
+    const unsigned long long total = (unsigned long long)J->units_per_image * (unsigned)batch;
+    if (total >= 0xffffffffull) return false;
+    J->total_units = (u32)total;
+    return true;
 }
 
 #define CHECK_DIMS()                                                                          \

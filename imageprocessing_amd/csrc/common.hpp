@@ -131,6 +131,7 @@ enum ProfStage {
     PROF_OPEN_H,
     PROF_BLUR,
     PROF_CANNY_NMS,
+    PROF_GRAY_CANNY,
     PROF_HYSTERESIS,
     PROF_HOUGH_COMPACT,
     PROF_HOUGH_VOTE,
@@ -208,10 +209,19 @@ size_t canny_ws_bytes(int w, int h, int batch);
 // run-time options (api.hip) read by the Canny launch
 int option_canny_bands();
 int option_canny_queue();
+int option_canny_wide();
 
 // flags_cleared: the area canny_flag_area() names has been zeroed by the caller (on the same stream)
+// nms_done: the codes (0 / WEAK / 255) and the tile flags are already in place (launch_canny_wide with a BGR source)
 int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, void* ws, size_t ws_bytes,
-              PointSink sink, hipStream_t st, bool flags_cleared = false);
+              PointSink sink, hipStream_t st, bool flags_cleared = false, bool nms_done = false);
+// The Canny strip kernel that writes whole aligned lines, alone (gray source) or fused with BGR -> gray /
+// threshold / bit plane (bgr_in).  np: 16-bit pixel pairs per lane, from canny_wide_np() (0 = not to be used).
+int canny_wide_np(int w, int h, int batch);
+bool canny_wide_fits(int w, int h, size_t src_pitch, size_t dst_pitch, size_t gray_pitch, size_t bin_pitch, int np);
+int launch_canny_wide(bool bgr_in, int np, Plane src, Plane gray, Plane bin, u32* bits, size_t bpw, size_t bsw, Plane dst, int w,
+                      int h, int batch, int ithresh, int maxval, int inv, int low, int high, void* canny_ws, ClearList clr,
+                      hipStream_t st);
 void canny_flag_area(int w, int h, int batch, void* ws, u32** p, u32* dwords);
 
 size_t hough_ws_bytes(int w, int h, int batch, int max_points);
@@ -224,6 +234,13 @@ int hough_segments(int numrho);
 enum HoughPhase { HOUGH_ALL = 0, HOUGH_VOTE_ONLY = 1, HOUGH_COMPACT_ONLY = 2, HOUGH_VOTE_ONLY_FOREIGN_LISTS = 3 };
 void hough_rowcount_area(int w, int h, int batch, int max_points, void* ws, u32** p, u32* dwords);
 // counts_cleared: point_counts has been zeroed by the caller (on the same stream)
+// job: a BGR -> gray conversion the vote kernel's spare waves may work on beside the vote (*job_done tells whether
+// they did; otherwise the caller launches it itself)
+struct GrayJob;
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
                     int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
-                    int resident_wgs, hipStream_t st, bool counts_cleared = false);
+                    int resident_wgs, hipStream_t st, bool counts_cleared = false, const GrayJob* job = nullptr,
+                    bool* job_done = nullptr);
+// the gray job of a front-end chunk (false: its shape needs the stand-alone kernel)
+bool gray_job_make(GrayJob* J, Plane bgr, Plane gray, Plane bin, u32* bits, size_t bpw, size_t bsw, int w, int h, int batch,
+                   int ithresh, int maxval, int inv);

@@ -14,6 +14,7 @@
 // separately (the file is built with -ffp-contract=off and uses __fmul_rn /
 // __fadd_rn), matching a scalar SSE build of OpenCV.
 #include "common.hpp"
+#include "gray_core.hpp"
 
 #include <math.h>
 #include <mutex>
@@ -381,10 +382,16 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_hough_vote(VoteArgs A, Trig T)
 // One angle per workgroup (TG = 1) is the shape of very large images, whose rho window only fits
 // once into a CU's LDS: that single workgroup has the registers of a whole CU, and it loads eight
 // trips ahead because nothing else on the CU hides the latency of its list.
-template <int TG, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(TG == 1 ? 4 : 8, 8)))  // TG > 1: two 1024-thread workgroups per CU
-void k_hough_vote_s(VoteArgs A, Trig T)
+// NG > 0: the last NG waves of the workgroup do not vote.  While the others work through the point list they
+// convert the workgroup's share of a BGR batch (GrayJob: the next part of a pipelined front-end pass) to gray,
+// thresholded plane and bit plane -- a streaming job bound by HBM beside the vote, which is bound by LDS atomics
+// and vector instructions and touches memory only for its list.  They join the others again for the parts every
+// thread shares (clearing and flushing the bins).  NTV = threads that vote.
+template <int TG, int NT, int NG>
+__device__ __forceinline__ void vote_body(const VoteArgs& A, const Trig& T, const GrayJob* J)
 {
+    constexpr int NTV = NT - 64 * NG;
+    static_assert(NTV >= 256 && NTV % 64 == 0, "whole waves vote");
     extern __shared__ __align__(16) u32 hist[];
     const int tid = threadIdx.x;
     // all workgroups of one image (they stream the same point list) on one XCD
@@ -429,6 +436,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     for (int i = tid; i < TG * span; i += NT) hist[i] = 0;
     __syncthreads();
 
+    if (NG == 0 || tid < NTV) {  // (wave-uniform) the waves that vote
     const u32 npts = min((u32)A.counts[b], A.cap);
     const u32* pts = A.pts + (size_t)b * A.pts_stride;
     const uint4* pts4 = (const uint4*)pts;
@@ -441,7 +449,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     constexpr int PF = TG == 1 ? 8 : VOTE_PREFETCH;
     // trips in which every lane has four points; a slice takes its share of them, the last slice
     // also what is left over behind them
-    const u32 all_trips = nfull / NT;
+    const u32 all_trips = nfull / NTV;
     const u32 trip0 = (u32)((unsigned long long)all_trips * (u32)slice / (u32)A.slices);
     const u32 trips = (u32)((unsigned long long)all_trips * (u32)(slice + 1) / (u32)A.slices) - trip0;
     const bool last_slice = slice == A.slices - 1;
@@ -461,7 +469,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         const float ca = fabsf(cg[tg > 1 ? 1 : 0]);
         comb_k = ca > 0.5f ? 2u : ca > 0.25f ? 4u : ca > 0.125f ? 8u : ca > 0.0625f ? 16u : ca > 0.03125f ? 32u : 64u;
         comb_k = (u32)__builtin_amdgcn_readfirstlane((int)comb_k);
-        if (16u * comb_k > 4u * NT) comb_k = 4;  // (a window holds at least one comb)
+        while (comb_k > 4 && (4u * NTV) % (16u * comb_k) != 0) comb_k >>= 1;  // (a window holds whole combs)
     }
     const u32 lane16 = (u32)tid & 15u, grp16 = (u32)tid >> 4;
     // two 8-byte loads: K >= 4: adjacent entries; K = 2: the second pair lies 32 entries further on
@@ -472,7 +480,7 @@ void k_hough_vote_s(VoteArgs A, Trig T)
     auto load4 = [&](u32 trip) -> uint4 {
         u32 t = trip + rot;  // trip < trips
         t = t >= trips ? t - trips : t;
-        const uint2* p2 = pts2 + (size_t)(trip0 + (t & A.dbg_trip_mask)) * (2u * NT);  // the trip's window
+        const uint2* p2 = pts2 + (size_t)(trip0 + (t & A.dbg_trip_mask)) * (2u * NTV);  // the trip's window
         const uint2 lo = p2[pair_lo], hi = p2[pair_hi];
         return make_uint4(lo.x, lo.y, hi.x, hi.y);
     };
@@ -510,10 +518,10 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         for (int k = 0; k < PF; k++)
             if (i + k < trips) cast4(buf[k]);
     }
-    if (last_slice && all_trips * NT + tid < nfull) cast4(pts4[all_trips * NT + tid]);
+    if (last_slice && all_trips * NTV + tid < nfull) cast4(pts4[all_trips * NTV + tid]);
     const u32 tail0 = last_slice ? nfull * 4 : npts;
     // the points left over by the four-at-a-time loop
-    for (u32 j = tail0 + tid; j < npts; j += NT) {
+    for (u32 j = tail0 + tid; j < npts; j += NTV) {
         const u32 p = pts[j];
         const float x = (float)(p & 0xffffu), y = (float)(p >> 16);
 #pragma unroll
@@ -526,11 +534,25 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         for (int g = 0; g < TG; g++)
             if (g < tg && byrow[g]) {
                 const int32_t* rc = A.rowcnt + (size_t)b * A.rowcnt_stride;
-                for (int yy = tid; yy < A.h; yy += NT) {
+                for (int yy = tid; yy < A.h; yy += NTV) {
                     const u32 nrow = (u32)rc[yy];
                     if (nrow) atomicAdd(&hist[g * span + rho_index(0.f, (float)yy, cg[g], sg[g]) + half + 1 - col0[g]], nrow);
                 }
             }
+    }
+    } else {
+        // the spare waves: this item's share of the gray job, unit by unit (a unit = 64 consecutive chunks).  They
+        // issue few instructions and wait for memory most of the time: with a raised priority their loads and
+        // stores go out as soon as they can, which keeps HBM busy beside the voting waves.
+        __builtin_amdgcn_s_setprio(3);
+        const u32 u0 = (u32)((unsigned long long)J->total_units * wg / A.items), u1 = (u32)((unsigned long long)J->total_units * (wg + 1) / A.items);
+        const u32 lane = (u32)tid & 63u;
+        for (u32 u = u0 + (u32)((tid - NTV) >> 6); u < u1; u += (u32)NG) {
+            const u32 bimg = u / J->units_per_image;
+            const u32 ci = (u - bimg * J->units_per_image) * 64u + lane;
+            if (ci < J->G.nchunks) gray_flat_chunk<true, true>(J->G, (int)bimg, ci);
+        }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
 
@@ -582,6 +604,20 @@ void k_hough_vote_s(VoteArgs A, Trig T)
         for (int col = tid; col < ncols; col += NT) acc[(size_t)(A.numangle + 1) * ncols + col] = 0;
     __syncthreads();  // the bins are cleared again for the next item
   }
+}
+
+template <int TG, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(TG == 1 ? 4 : 8, 8)))  // TG > 1: two 1024-thread workgroups per CU
+void k_hough_vote_s(VoteArgs A, Trig T)
+{
+    vote_body<TG, NT, 0>(A, T, nullptr);
+}
+
+template <int TG, int NT, int NG>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_hough_vote_gray(VoteArgs A, Trig T, GrayJob J)
+{
+    vote_body<TG, NT, NG>(A, T, &J);
 }
 
 // Four cells per lane and trip (independent loads); the four neighbours are read only for
@@ -855,8 +891,9 @@ static bool raster_lists(int batch, int numangle)
 
 int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta, int32_t* accum, size_t accum_stride,
                     int32_t* seg_max, int max_points, int32_t* point_counts, void* ws, size_t ws_bytes, int phase,
-                    int resident_wgs, hipStream_t st, bool counts_cleared)
+                    int resident_wgs, hipStream_t st, bool counts_cleared, const GrayJob* job, bool* job_done)
 {
+    if (job_done) *job_done = false;
     IPA_REQUIRE(w <= 65535 && h <= 65535, IPA_ERR_ARG, "HoughLines: image larger than 65535 pixels on a side");
     int numangle, numrho;
     hough_dims(w, h, rho, theta, &numangle, &numrho);
@@ -1076,6 +1113,8 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_s<8, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_gray<4, 1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        IPA_HIP(hipFuncSetAttribute((const void*)k_hough_vote_gray<4, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         g_vote_attr_set = true;
     }
     ProfScope ps(PROF_HOUGH_VOTE, st);
@@ -1102,6 +1141,20 @@ int run_hough_accum(Plane src, int w, int h, int batch, double rho, double theta
         }
         const int resident = (resident_env > 0 ? resident_env : resident_wgs) & ~7;
         const dim3 grid_s(resident > 0 && (u32)resident < Ab.items ? (unsigned)resident : Ab.items);
+        // a gray job rides along on four of the sixteen waves of the batch shape (four angles, 1024 threads, one slice)
+        static int job_waves = -1;  // IPA_VOTE_GRAY_WAVES: 0 = never, 2 or 4 (default) spare waves
+        if (job_waves < 0) {
+            const char* e = getenv("IPA_VOTE_GRAY_WAVES");
+            job_waves = e ? atoi(e) : 4;
+            if (job_waves != 0 && job_waves != 2) job_waves = 4;
+        }
+        if (job && job_waves && tgs == 4 && vote_nt == 1024 && A.slices == 1 && resident == 0 && b0 == 0 && nb == batch) {
+            if (job_waves == 4) hipLaunchKernelGGL((k_hough_vote_gray<4, 1024, 4>), grid_s, dim3(1024), lds, st, Ab, T, *job);
+            else hipLaunchKernelGGL((k_hough_vote_gray<4, 1024, 2>), grid_s, dim3(1024), lds, st, Ab, T, *job);
+            IPA_LAUNCH_CHECK();
+            if (job_done) *job_done = true;
+            continue;
+        }
 #define IPA_VOTE_S(TGV)                                                                               \
     do {                                                                                              \
         if (vote_nt == 1024)                                                                          \

@@ -13,6 +13,7 @@ STAGE_OF = {
     "k_hyst_tiles": "canny_hysteresis", "k_hyst_final": "canny_hysteresis", "k_hough_compact": "hough_compact",
     "k_hough_vote": "hough_vote", "k_hough_vote_s": "hough_vote", "k_hough_peaks": "hough_peaks",
     "k_hough_peaks_seg": "hough_peaks", "k_hough_compact2": "hough_compact", "k_gauss5_stream": "gaussian_blur",
+    "k_canny_wide": "gray_thresh_canny",
 }
 
 

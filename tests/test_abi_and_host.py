@@ -57,7 +57,7 @@ def test_host_side_helpers_without_gpu():
     assert L.ipa_canny_workspace_bytes(3840, 2160, 2) > 0
     assert L.ipa_front_end_workspace_bytes(1920, 1080, 1, 0) > L.ipa_front_end_workspace_bytes(1920, 1080, 1, 1000)
     assert L.ipa_morph_workspace_bytes(0, 10, 1) == 0
-    assert L.ipa_profile_stage_count() == 9
+    assert L.ipa_profile_stage_count() == 10
     assert L.ipa_profile_stage_name(0) == b"gray_thresh_pack"
 
 

@@ -660,6 +660,56 @@ def test_front_end_large_batch_runs_in_chunks(n, hough, chunks, phased):
         _check_front_end(single, batch[i], 140, 15, 15, 2, 50, 150, False)
 
 
+@pytest.mark.parametrize("vote_gray,canny_wide,blur", [(1, 0, False), (2, 0, False), (1, 0, True), (0, 4, False), (0, 8, False),
+                                                        (1, 8, False)])
+def test_front_end_kernel_variants_behind_options(vote_gray, canny_wide, blur):
+    # vote_gray: the binarisation of chunk c + 1 done by spare waves of the vote kernel of chunk c (2: the opens one
+    # phase later); canny_wide: gray, threshold, bit plane and Canny's non-maximum suppression in one kernel that
+    # writes whole aligned lines (widths that are multiples of 8 / 16 pixels).  Results never depend on them.
+    n, h, w = 70, 72, 112
+    batch = np.stack([uml_like(3100 + i, h, w, noise=(3 if i % 3 == 0 else 0)) for i in range(n)])
+    cv2.set_option("pipeline_chunks", 3)
+    cv2.set_option("vote_gray", vote_gray)
+    cv2.set_option("canny_wide", canny_wide)
+    try:
+        res = cv2.front_end_batch(batch, thresh_val=140, hough=True, blur=blur)
+        one = cv2.Canny(fr.bgr2gray(batch[1]), 50, 150)  # (the gray-input form of the wide kernel)
+    finally:
+        cv2.set_option("pipeline_chunks", -1)
+        cv2.set_option("vote_gray", 0)
+        cv2.set_option("canny_wide", 0)
+    assert np.array_equal(one, fr.canny(fr.bgr2gray(batch[1]), 50, 150))
+    for i in range(n):
+        single = cv2.FrontEndResult(res.gray[i], res.thresh[i], res.vlines[i], res.hlines[i], res.edges[i], res.accum[i])
+        _check_front_end(single, batch[i], 140, 15, 15, 2, 50, 150, blur)
+
+
+def test_canny_wide_kernel_shapes():
+    # the strip kernel that writes whole aligned lines: strips that end inside a lane group, images narrower than a
+    # strip, bands that end in the middle of the image, dense candidates (stack pops in every row) and flat pages
+    cases = []
+    for h, w in ((70, 256), (64, 1040), (130, 512), (200, 1536), (33, 128), (3, 16), (1, 704), (300, 32), (129, 2064)):
+        cases.append((rand_gray(h * 3 + w, h, w), (50, 150)))
+        cases.append((rand_gray(h + w, h, w), (0, 300)))
+        cases.append((smooth_gray(h + w * 5, h, w), (10, 40)))
+        cases.append((np.full((h, w), 200, np.uint8), (50, 150)))
+    cases.append((fr.bgr2gray(uml_like(9100, 704, 1296)), (50, 150)))
+    for np_ in (4, 8):
+        cv2.set_option("canny_wide", np_)
+        try:
+            for g, (lo, hi) in cases:
+                assert np.array_equal(cv2.Canny(g, lo, hi), fr.canny(g, lo, hi)), (np_, g.shape, lo, hi)
+            bgr = np.stack([uml_like(9300 + i, 260, 704, noise=3 * (i % 2)) for i in range(5)])
+            r = cv2.front_end_batch(bgr, hough=False)
+            for i in range(5):
+                g = fr.bgr2gray(bgr[i])
+                assert np.array_equal(r.gray[i], g) and np.array_equal(r.thresh[i], fr.threshold(g, 128, 255, 1)[1])
+                assert np.array_equal(r.edges[i], fr.canny(g, 50, 150)), (np_, i)
+                assert np.array_equal(r.vlines[i], fr.morphology_ex(r.thresh[i], 2, (1, 15), 2))
+        finally:
+            cv2.set_option("canny_wide", 0)
+
+
 def test_hough_single_large_image_uses_list_slices():
     # a single image of >= 4 Mpx: the point list is cut into slices that add into a zeroed accumulator
     bgr = uml_like(77, 2048, 2176)
