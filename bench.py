@@ -399,6 +399,31 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launch_ms": stages[dom]["ms"], "algorithmic_bytes_per_launch": alg[dom] * batch}
+            # The whole step against its two floors, from the counters of the serial schedule (per image and stage,
+            # scaled by the batch): every VALU wave instruction holds its SIMD for at least 4 clocks, every HBM
+            # byte costs 1/peak.  Stages overlap in the timed steps, so both floors bound the step, not their sum.
+            try:
+                props = torch.cuda.get_device_properties(dev)
+                vj = tj.get("valu_per_image", {}).get(args.size, {})
+                pj = tj.get("per_image", {}).get(args.size, {})
+                ran = [nm for nm in stages if nm in vj]
+                if ran:
+                    instr = sum(vj[nm] for nm in ran) * batch
+                    simds = 4 * props.multi_processor_count
+                    clock_hz = 2.4e9  # engine clock of the MI355X
+                    floor_ms = instr * 4.0 / (simds * clock_hz) * 1e3
+                    step_ms = elapsed / args.steps * 1e3
+                    hbm = sum(pj.get(nm, 0.0) for nm in stages) * batch
+                    roof["valu"] = {"wave_instructions_per_step": round(instr), "issue_floor_ms": round(floor_ms, 3),
+                                    "frac_of_step": round(floor_ms / step_ms, 4),
+                                    "per_stage_G": {nm: round(vj[nm] * batch / 1e9, 3) for nm in ran},
+                                    "hbm_traffic_bytes_per_step": round(hbm),
+                                    "hbm_floor_ms": round(hbm / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+                                    "note": "SQ_INSTS_VALU and 2 x FETCH_SIZE + WRITE_SIZE per stage (rocprofv3 --pmc, serial "
+                                            "schedule, profiles/traffic.json); floor = 4 clk per wave instruction on "
+                                            f"{simds} SIMDs at 2.4 GHz"}
+            except Exception:
+                pass
             if "hough_vote" in stages and stages["hough_vote"]["ms"] > 0 and fe.hough:
                 # The vote is bound by LDS atomics, not by HBM: also quote it against the LDS atomic rates measured on
                 # this chip with 16 waves per CU (scripts/micro/lds_rate.hip, lds_rand.hip; clocks at 2.4 GHz):

@@ -243,83 +243,139 @@ __global__ __launch_bounds__(256) void k_bytewise(Plane src, Plane src2, Plane d
     }
 }
 
-// 256-bin histogram.  Each wave keeps a private LDS histogram.  A white page is
-// ~97 % one value, so the common case is a wave whose 1024 pixels are all equal:
-// that is detected with a wave vote and costs one LDS atomic instead of 1024.
+// 256-bin histogram.  A wave whose 1024 pixels all hold one value (a white page is ~97 % one value) is detected
+// with a wave vote and costs one LDS atomic.  Otherwise every lane adds its 16 bytes one by one into one of sixteen
+// copies of the histogram that the workgroup keeps in LDS, copy = lane mod 16, stored interleaved (word = 16 value +
+// copy): lanes that hold the same value -- on a noisy scan most of a wave does -- then hit sixteen different words
+// in sixteen different banks instead of one address sixty-four times (atomics of one instruction that share an
+// address are served one after the other), and neighbouring values fall into the other half of the banks.
+constexpr int HIST_COPIES = 16;
+// div_k != 0: the image has fewer than 2^28 chunks and row = chunk / cpr is a multiplication (div_m = floor(2^div_k / cpr) + 1)
 __global__ __launch_bounds__(256) void k_hist(Plane src, int w, int h, int cpr, long long chunks_per_img,
-                                              u32* __restrict__ hist)
+                                              u32* __restrict__ hist, u32 div_m, int div_k)
 {
-    __shared__ u32 lh[4][256];
+    __shared__ u32 lh[256 * HIST_COPIES];
     const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&lh[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 256 * HIST_COPIES; i += 256) lh[i] = 0;
     __syncthreads();
+    char* const mine = (char*)lh + (threadIdx.x & (HIST_COPIES - 1)) * 4;  // this lane's copy
     const long long step = (long long)gridDim.x * blockDim.x;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < chunks_per_img; base += step) {
-        long long c = base + threadIdx.x;
-        int n = 0;
-        u32 d[4] = {0, 0, 0, 0};
-        if (c < chunks_per_img) {
-            int cx = (int)(c % cpr), y = (int)(c / cpr);
-            n = min(16, w - cx * 16);
-            uint4 a = *(const uint4*)(src.row(b, y) + (size_t)cx * 16);
-            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-        }
-        u32 first = d[0] & 0xffu;
-        u32 rep = first * 0x01010101u;
-        bool same = n == 16 && d[0] == rep && d[1] == rep && d[2] == rep && d[3] == rep;
-        u32 lead = __shfl(first, 0);
-        if (__all(same && first == lead)) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(&lh[wave][lead], 1024u);
+    const u8* const img = src.p + (size_t)b * src.stride;
+    // the chunk of the next trip is loaded before the current one is counted
+    auto fetch = [&](long long c, int& n) -> uint4 {
+        n = 0;
+        if (c >= chunks_per_img) return make_uint4(0, 0, 0, 0);
+        int cx, y;
+        if (div_k) {
+            y = (int)(((unsigned long long)(u32)c * div_m) >> div_k);
+            cx = (int)((u32)c - (u32)y * (u32)cpr);
         } else {
-            // merge runs of equal bytes before touching LDS
-            u32 cur = first, run = 0;
-            for (int i = 0; i < n; i++) {
-                u32 v = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                if (v == cur) {
-                    run++;
-                } else {
-                    atomicAdd(&lh[wave][cur], run);
-                    cur = v;
-                    run = 1;
-                }
+            cx = (int)(c % cpr);
+            y = (int)(c / cpr);
+        }
+        n = min(16, w - cx * 16);
+        return *(const uint4*)(img + (size_t)y * src.pitch + (size_t)cx * 16);
+    };
+    int n_next;
+    uint4 a_next = fetch((long long)blockIdx.x * blockDim.x + threadIdx.x, n_next);
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < chunks_per_img; base += step) {
+        const uint4 a = a_next;
+        const int n = n_next;
+        a_next = fetch(base + step + threadIdx.x, n_next);
+        const u32 d[4] = {a.x, a.y, a.z, a.w};
+        const u32 first = d[0] & 0xffu;
+        const u32 rep = first * 0x01010101u;
+        const bool same = n == 16 && d[0] == rep && d[1] == rep && d[2] == rep && d[3] == rep;
+        const u32 lead = __shfl(first, 0);
+        if (__all(same && first == lead)) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&lh[lead * HIST_COPIES], 1024u);
+        } else if (n == 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u32 v = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                atomicAdd((u32*)(mine + v * (HIST_COPIES * 4)), 1u);
             }
-            if (run) atomicAdd(&lh[wave][cur], run);
+        } else {
+            for (int i = 0; i < n; i++) {
+                const u32 v = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                atomicAdd((u32*)(mine + v * (HIST_COPIES * 4)), 1u);
+            }
         }
     }
     __syncthreads();
-    u32 s = lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < HIST_COPIES; k++) s += lh[threadIdx.x * HIST_COPIES + k];
     if (s) atomicAdd(&hist[(size_t)b * 256 + threadIdx.x], s);
 }
 
-// Otsu's threshold from a 256-bin histogram: OpenCV's sequential scan in double
-// precision (one lane per image; 256 steps).
-__global__ void k_otsu_scan(const u32* __restrict__ hist, int batch, long long npix, int32_t* __restrict__ out)
+// Otsu's threshold from a 256-bin histogram, with the results of OpenCV's sequential scan in double precision.  One
+// workgroup of 256 threads per image.  The mean is a sum of integers below 2^53 and therefore exact in any order
+// (wave reduction).  The running class weight q1 and class mean mu1 form the only sequential chain (one multiply,
+// one add and one division per grey level): lane 0 walks it over the histogram in LDS and leaves q1 and mu1 of
+// every level there; the between-class variance of all levels is then evaluated side by side, with the expression
+// of the scan, and the first level that reaches the largest variance wins, as the scan's strict comparison does.
+__global__ __launch_bounds__(256) void k_otsu_scan(const u32* __restrict__ hist, long long npix, int32_t* __restrict__ out)
 {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const u32* hgram = hist + (size_t)b * 256;
-    double mu = 0, scale = 1.0 / (double)npix;
-    for (int i = 0; i < 256; i++) mu += i * (double)hgram[i];
-    mu *= scale;
-    double mu1 = 0, q1 = 0, max_sigma = 0;
-    int max_val = 0;
-    for (int i = 0; i < 256; i++) {
-        double p_i = hgram[i] * scale;
-        mu1 *= q1;
-        q1 += p_i;
-        double q2 = 1. - q1;
-        if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
-        mu1 = (mu1 + i * p_i) / q1;
-        double mu2 = (mu - q1 * mu1) / q2;
-        double d = mu1 - mu2;
-        double sigma = q1 * q2 * d * d;
-        if (sigma > max_sigma) {
-            max_sigma = sigma;
-            max_val = i;
+    __shared__ double s_p[256], s_q1[256], s_mu1[256], s_red[256];
+    __shared__ u32 s_valid[8];
+    const int b = blockIdx.x, i = threadIdx.x;
+    const double scale = 1.0 / (double)npix;
+    const u32 hi_ = hist[(size_t)b * 256 + i];
+    s_p[i] = hi_ * scale;
+    s_red[i] = i * (double)hi_;
+    if (i < 8) s_valid[i] = 0;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (i < o) s_red[i] += s_red[i + o];
+        __syncthreads();
+    }
+    const double mu = s_red[0] * scale;
+    if (i == 0) {
+        double mu1 = 0, q1 = 0;
+        u32 vbits = 0;
+        for (int k = 0; k < 256; k++) {
+            const double p_k = s_p[k];
+            mu1 *= q1;
+            q1 += p_k;
+            const double q2 = 1. - q1;
+            const bool ok = !(fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON);
+            if (ok) mu1 = (mu1 + k * p_k) / q1;
+            s_q1[k] = q1;
+            s_mu1[k] = mu1;
+            vbits |= ok ? 1u << (k & 31) : 0u;
+            if ((k & 31) == 31) {
+                s_valid[k >> 5] = vbits;
+                vbits = 0;
+            }
         }
     }
-    out[b] = max_val;
+    __syncthreads();
+    double sigma = -1.0;  // (levels the scan skips never win: the scan starts from a largest variance of 0)
+    if ((s_valid[i >> 5] >> (i & 31)) & 1u) {
+        const double q1 = s_q1[i], mu1 = s_mu1[i];
+        const double q2 = 1. - q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double d = mu1 - mu2;
+        sigma = q1 * q2 * d * d;
+    }
+    __syncthreads();
+    s_red[i] = sigma;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (i < o) s_red[i] = fmax(s_red[i], s_red[i + o]);
+        __syncthreads();
+    }
+    const double best = s_red[0];
+    __syncthreads();
+    // first level with the largest variance (none when no variance is above 0: level 0, as the scan's initial value)
+    s_red[i] = (best > 0 && sigma == best) ? (double)i : 256.0;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (i < o) s_red[i] = fmin(s_red[i], s_red[i + o]);
+        __syncthreads();
+    }
+    if (i == 0) out[b] = s_red[0] < 256.0 ? (int)s_red[0] : 0;
 }
 
 int sat_u8_round(double v)
@@ -571,7 +627,7 @@ static int histogram_impl(Plane s, int width, int height, int batch, u32* hist, 
     int cpr = cdiv(width, 16);
     long long cpi = (long long)cpr * height;
     unsigned gx = (unsigned)((cpi + 256 * 8 - 1) / (256 * 8));
-    unsigned cap = (unsigned)(4096 / (batch < 4096 ? batch : 4096));
+    unsigned cap = (unsigned)(1024 / (batch < 1024 ? batch : 1024));  // (few workgroups: every one ends with an atomic per non-empty bin on the image's 256 counters)
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
@@ -579,7 +635,15 @@ static int histogram_impl(Plane s, int width, int height, int batch, u32* hist, 
         int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         Plane sb = s;
         sb.p += (size_t)b0 * s.stride;
-        hipLaunchKernelGGL(k_hist, dim3(gx, nb), dim3(256), 0, st, sb, width, height, cpr, cpi, hist + (size_t)b0 * 256);
+        u32 div_m = 0;
+        int div_k = 0;
+        if ((unsigned long long)cpi < (1ull << 28)) {
+            int lb = 0;
+            while ((1u << lb) <= (u32)cpr) lb++;  // cpr < 2^lb
+            div_k = 28 + lb;
+            div_m = (u32)((1ull << div_k) / (u32)cpr) + 1u;
+        }
+        hipLaunchKernelGGL(k_hist, dim3(gx, nb), dim3(256), 0, st, sb, width, height, cpr, cpi, hist + (size_t)b0 * 256, div_m, div_k);
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;
@@ -613,8 +677,7 @@ IPA_EXPORT int ipa_threshold_otsu_u8(const uint8_t* src, size_t src_pitch, size_
     hipStream_t st = (hipStream_t)stream;
     int rc = histogram_impl(s, width, height, batch, hist, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_otsu_scan, dim3(cdiv(batch, 64)), dim3(64), 0, st, hist, batch, (long long)width * height,
-                       otsu);
+    hipLaunchKernelGGL(k_otsu_scan, dim3((unsigned)batch), dim3(256), 0, st, hist, (long long)width * height, otsu);
     IPA_LAUNCH_CHECK();
     return threshold_impl(s, d, width, height, batch, 0, otsu, maxval, type & 7, st);
 }

@@ -96,8 +96,20 @@ __global__ __launch_bounds__(256) void k_hough_compact(Plane src, int w, int h, 
 // block holds more than the stage).
 constexpr int CP_STAGE = 4096;
 
-// bit 0 of each byte of x -> 4 adjacent bits
-__device__ __forceinline__ u32 bytes_to_bits(u32 x) { return ((x & 0x01010101u) * 0x10204080u) >> 28; }
+// bytes of 0 / 1 -> 4 adjacent bits (one dot product instead of a 32-bit multiply)
+__device__ __forceinline__ u32 bytes_to_bits(u32 x) { return __builtin_amdgcn_udot4(x, 0x08040201u, 0u, false); }
+// inclusive sum over the 64 lanes of a wave with cross-lane adds only (no LDS permutes): four shifts inside
+// each row of 16 lanes, then lane 15 of a row into the next row and lane 31 into the upper half
+__device__ __forceinline__ u32 wave_scan_add(u32 v)
+{
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
 // 1 in bit 0 of every non-zero byte
 __device__ __forceinline__ u32 nonzero_bytes(u32 v) { return ((v | ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; }
 
@@ -131,12 +143,7 @@ __global__ __launch_bounds__(64 * NW) void k_hough_compact2(Plane src, int w, in
         m[k] = (bytes_to_bits(nonzero_bytes(a[k].x)) | (bytes_to_bits(nonzero_bytes(a[k].y)) << 4) |
                 (bytes_to_bits(nonzero_bytes(a[k].z)) << 8) | (bytes_to_bits(nonzero_bytes(a[k].w)) << 12)) & keep;
         const u32 cnt = __popc(m[k]);
-        u32 scan = cnt;  // inclusive scan over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = __shfl_up(scan, o);
-            if (lane >= o) scan += t;
-        }
+        const u32 scan = wave_scan_add(cnt);
         excl[k] = scan - cnt;
         if (lane == 63) row_tot[wave * ROWS_PER_LANE + k] = scan;
     }

@@ -91,17 +91,20 @@ def front_end_sharded(images, devices: Sequence[int] = None, max_batch: int = 25
     """The fused front-end of a batch uint8[N,H,W,3] (host array) over several GPUs from ONE process:
     the batched replacement of the per-file loop of receiveFile.py:22 when one process owns the node.
 
-    Images are split by index (``plan_shards``); every device slot has a host thread, a stream and
-    page-locked staging of its own and runs ``front_end_batch`` on its blocks; the per-image results
-    come back as host arrays concatenated in image order (host gather, no collective).  ``devices``
-    defaults to all visible GPUs; a device may be listed more than once (several streams on it).
-    Keyword arguments are those of ``front_end_batch``; returns a ``FrontEndResult`` of numpy arrays
+    Images are split by index (``plan_shards``); every device slot has a host thread, a stream, ONE
+    planned ``FrontEnd`` per block length (the full blocks share one, a shorter last block gets its own)
+    and one pair of page-locked staging buffers, all reused over the slot's blocks; uploads and downloads
+    are asynchronous copies on the slot's stream with a single synchronisation per block.  The per-image
+    results come back as host arrays concatenated in image order (host gather, no collective).
+    ``devices`` defaults to all visible GPUs; a device may be listed more than once (several streams on
+    it).  Keyword arguments are those of ``front_end_batch``; returns a ``FrontEndResult`` of numpy arrays
     (``accum`` as a host array too)."""
     import threading
 
     import torch
 
     from . import pipeline
+    from ._device import DevImage
 
     imgs = np.asarray(images)
     if imgs.ndim != 4 or imgs.shape[3] != 3 or imgs.dtype != np.uint8:
@@ -112,6 +115,8 @@ def front_end_sharded(images, devices: Sequence[int] = None, max_batch: int = 25
         raise RuntimeError("front_end_sharded: no GPU visible (there is no CPU path)")
     n, h, w = int(imgs.shape[0]), int(imgs.shape[1]), int(imgs.shape[2])
     work = plan_shards(n, len(devices), max_batch)
+    kw = dict(kw)
+    hough_threshold = kw.pop("hough_threshold", None)
     hough = kw.get("hough", True)
     edges = kw.get("edges", True) or hough
     planes = [np.empty((n, h, w), np.uint8) if (k < 4 or edges) else None for k in range(5)]
@@ -121,26 +126,44 @@ def front_end_sharded(images, devices: Sequence[int] = None, max_batch: int = 25
 
     def run_slot(slot: int):
         try:
+            blocks = [(lo, hi) for d, lo, hi in work if d == slot and hi > lo]
+            if not blocks or h * w == 0:
+                return
+            bmax = max(hi - lo for lo, hi in blocks)
             dev = torch.device("cuda", int(devices[slot]))
             with torch.cuda.device(dev):
                 st = torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(st):
-                    for d, lo, hi in work:
-                        if d != slot or hi <= lo:
-                            continue
-                        pin = torch.empty((hi - lo, h, w, 3), dtype=torch.uint8, pin_memory=True)
-                        pin.numpy()[...] = imgs[lo:hi]
-                        res = pipeline.front_end_batch(pin.to(dev, non_blocking=True), **kw)
-                        for k, pl in enumerate((res.gray, res.thresh, res.vlines, res.hlines, res.edges)):
-                            if pl is not None:
-                                planes[k][lo:hi] = pl.cpu().numpy()
-                        if res.accum is not None:
-                            a = res.accum.cpu().numpy()
+                    plans = {}  # block length -> FrontEnd (planes, accumulators and workspace of its own)
+                    pin_in = torch.empty((bmax, h, w * 3), dtype=torch.uint8, pin_memory=True)
+                    pin_out = torch.empty((5, bmax, h, w), dtype=torch.uint8, pin_memory=True)
+                    dev_in = DevImage.empty(bmax, h, w, 3)
+                    pin_acc = None
+                    for lo, hi in blocks:
+                        nb = hi - lo
+                        fe = plans.get(nb)
+                        if fe is None:
+                            fe = plans[nb] = pipeline.FrontEnd(nb, h, w, **kw)
+                            if fe.hough and pin_acc is None:
+                                pin_acc = torch.empty((bmax, fe.na + 2, fe.nr + 2), dtype=torch.int32, pin_memory=True)
+                        pin_in.numpy()[:nb] = imgs[lo:hi].reshape(nb, h, w * 3)
+                        dev_in.t[:nb, :, : w * 3].copy_(pin_in[:nb], non_blocking=True)
+                        fe.run(DevImage(dev_in.t[:nb], nb, h, w, 3))
+                        for k in range(5):
+                            if planes[k] is not None:
+                                pin_out[k, :nb].copy_(fe.plane(k).valid(), non_blocking=True)
+                        if fe.hough:
+                            pin_acc[:nb].copy_(fe.accum[:nb], non_blocking=True)
+                        st.synchronize()  # the one wait of the block: staging is free again after it
+                        for k in range(5):
+                            if planes[k] is not None:
+                                planes[k][lo:hi] = pin_out[k, :nb].numpy()
+                        if fe.hough:
+                            a = pin_acc[:nb].numpy().copy()
                             for i in range(lo, hi):
                                 accum[i] = a[i - lo]
-                        if res.lines is not None:
-                            lines[lo:hi] = res.lines
-                    st.synchronize()
+                            if hough_threshold is not None:
+                                lines[lo:hi] = fe.lines(hough_threshold)
         except BaseException as ex:  # re-raised by the caller's thread
             errors.append(ex)
 
@@ -153,4 +176,4 @@ def front_end_sharded(images, devices: Sequence[int] = None, max_batch: int = 25
         raise errors[0]
     acc = np.stack(accum) if (hough and n) else None
     return pipeline.FrontEndResult(planes[0], planes[1], planes[2], planes[3], planes[4], accum=acc,
-                                   lines=lines if kw.get("hough_threshold") is not None and hough else None)
+                                   lines=lines if hough_threshold is not None and hough else None)

@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="", help="substring of the operations to run")
     args = ap.parse_args()
     import torch
 
@@ -48,6 +49,8 @@ def main():
         ("full front-end, variant B (blur 5x5), lines 101 it=2, Hough", 8 + 4.0 * 182 * (4 * s + 3) / px, lambda: fe.enqueue(dev_bgr)),
     ]
     for name, bpp, fn in ops:
+        if args.only and args.only not in name:
+            continue
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

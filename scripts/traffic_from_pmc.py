@@ -3,7 +3,7 @@ per launch (bytes), written as profiles/traffic.json -> {"<size>x<batch>": {stag
 
 FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced
 streaming read at half its bytes (128-B requests tallied as 64 B), so it is doubled here;
-WRITE_SIZE is taken as is.
+WRITE_SIZE is taken as is.  The SQ_INSTS_VALU pass (wave instructions) goes into "valu_per_image" the same way.
 usage: traffic_from_pmc.py <pmc dir> <key e.g. 4kx128> [out json]"""
 import collections, csv, glob, json, os, re, sys
 
@@ -48,13 +48,21 @@ def main():
     if os.path.exists(out):
         data = json.load(open(out))
     data[key] = {s: round(v) for s, v in stage.items()}
+    valu = collections.defaultdict(float)
+    for k, v in per_kernel(os.path.join(root, "sq2"), "SQ_INSTS_VALU").items():
+        if k in STAGE_OF and v:
+            valu[STAGE_OF[k]] += sum(v) / len(v)
     m = re.fullmatch(r"(\w+?)x(\d+)", key)
     if m:  # bytes per image and stage: what bench.py scales by its own batch
         data.setdefault("per_image", {})[m.group(1)] = {s: v / int(m.group(2)) for s, v in stage.items()}
+        if valu:  # VALU wave instructions per image and stage
+            data.setdefault("valu_per_image", {})[m.group(1)] = {s: v / int(m.group(2)) for s, v in valu.items()}
     data.setdefault("_note", "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), rocprofv3 --pmc, separate passes")
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     for k, n, f, w in rows:
         print(f"{k:20s} launches={n:4d} fetch={f/1e6:10.1f} MB  write={w/1e6:10.1f} MB")
+    for s, v in sorted(valu.items()):
+        print(f"valu {s:20s} {v/1e9:8.3f} G wave instructions per launch")
 
 
 if __name__ == "__main__":
