@@ -75,6 +75,11 @@ size_t ipa_pitch_for(size_t row_bytes);
  *                                        (default), 16 or 64 = forced
  *   "canny_queue"      [IPA_CANNY_QUEUE] 0 = non-maximum suppression in place in every row instead
  *                                        of deferred through a per-wave LDS stack (64-row bands)
+ *   "canny_wide"       [IPA_CANNY_WIDE]  0 = strip kernel (default); 4 or 8 = the Canny kernel that writes whole
+ *                                        aligned lines, with that many pixel pairs per lane (fused with the BGR
+ *                                        conversion inside ipa_front_end_u8); -1 = that kernel for large launches
+ *   "vote_gray"        [IPA_VOTE_GRAY]   0 = default; 1 = in the phased schedule the gray conversion of the next
+ *                                        chunk runs on spare waves of the vote kernel; 2 = as 1, opens one phase later
  * Results do not depend on any of them.  Settings apply to the calls that follow, from any thread. */
 int ipa_set_option(const char* name, int value);
 int ipa_get_option(const char* name, int* value);
