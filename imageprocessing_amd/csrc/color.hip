@@ -251,12 +251,13 @@ __global__ __launch_bounds__(256) void k_bytewise(Plane src, Plane src2, Plane d
 // address are served one after the other), and neighbouring values fall into the other half of the banks.
 constexpr int HIST_COPIES = 16;
 // div_k != 0: the image has fewer than 2^28 chunks and row = chunk / cpr is a multiplication (div_m = floor(2^div_k / cpr) + 1)
-__global__ __launch_bounds__(256) void k_hist(Plane src, int w, int h, int cpr, long long chunks_per_img,
-                                              u32* __restrict__ hist, u32 div_m, int div_k)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hist(Plane src, int w, int h, int cpr, long long chunks_per_img,
+                                             u32* __restrict__ hist, u32 div_m, int div_k)
 {
     __shared__ u32 lh[256 * HIST_COPIES];
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 256 * HIST_COPIES; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < 256 * HIST_COPIES; i += NT) lh[i] = 0;
     __syncthreads();
     char* const mine = (char*)lh + (threadIdx.x & (HIST_COPIES - 1)) * 4;  // this lane's copy
     const long long step = (long long)gridDim.x * blockDim.x;
@@ -276,12 +277,16 @@ __global__ __launch_bounds__(256) void k_hist(Plane src, int w, int h, int cpr, 
         n = min(16, w - cx * 16);
         return *(const uint4*)(img + (size_t)y * src.pitch + (size_t)cx * 16);
     };
-    int n_next;
+    // the chunks of the next two trips are under way while the current one is counted
+    int n_next, n_next2;
     uint4 a_next = fetch((long long)blockIdx.x * blockDim.x + threadIdx.x, n_next);
+    uint4 a_next2 = fetch((long long)blockIdx.x * blockDim.x + step + threadIdx.x, n_next2);
     for (long long base = (long long)blockIdx.x * blockDim.x; base < chunks_per_img; base += step) {
         const uint4 a = a_next;
         const int n = n_next;
-        a_next = fetch(base + step + threadIdx.x, n_next);
+        a_next = a_next2;
+        n_next = n_next2;
+        a_next2 = fetch(base + 2 * step + threadIdx.x, n_next2);
         const u32 d[4] = {a.x, a.y, a.z, a.w};
         const u32 first = d[0] & 0xffu;
         const u32 rep = first * 0x01010101u;
@@ -303,21 +308,26 @@ __global__ __launch_bounds__(256) void k_hist(Plane src, int w, int h, int cpr, 
         }
     }
     __syncthreads();
-    u32 s = 0;
+    if (threadIdx.x < 256) {
+        u32 s = 0;
 #pragma unroll
-    for (int k = 0; k < HIST_COPIES; k++) s += lh[threadIdx.x * HIST_COPIES + k];
-    if (s) atomicAdd(&hist[(size_t)b * 256 + threadIdx.x], s);
+        for (int k = 0; k < HIST_COPIES; k++) s += lh[threadIdx.x * HIST_COPIES + k];
+        if (s) atomicAdd(&hist[(size_t)b * 256 + threadIdx.x], s);
+    }
 }
 
 // Otsu's threshold from a 256-bin histogram, with the results of OpenCV's sequential scan in double precision.  One
 // workgroup of 256 threads per image.  The mean is a sum of integers below 2^53 and therefore exact in any order
-// (wave reduction).  The running class weight q1 and class mean mu1 form the only sequential chain (one multiply,
-// one add and one division per grey level): lane 0 walks it over the histogram in LDS and leaves q1 and mu1 of
-// every level there; the between-class variance of all levels is then evaluated side by side, with the expression
-// of the scan, and the first level that reaches the largest variance wins, as the scan's strict comparison does.
+// (wave reduction).  What is sequential in the scan is split by what it depends on: the running class weight q1 is a
+// chain of additions (one lane, first); whether a level is skipped, the product k * p_k and the reciprocal of q1
+// refined by two Newton steps depend on q1 alone and are made side by side for all levels; the class mean mu1 is then
+// a chain of five dependent operations per level (multiply, add, quotient estimate, two fused corrections) -- the
+// same operations, in the same order and with the same roundings, as the multiply, add and division of the scan.
+// The between-class variance of all levels is evaluated side by side with the expression of the scan, and the
+// first level that reaches the largest variance wins, as the scan's strict comparison does.
 __global__ __launch_bounds__(256) void k_otsu_scan(const u32* __restrict__ hist, long long npix, int32_t* __restrict__ out)
 {
-    __shared__ double s_p[256], s_q1[256], s_mu1[256], s_red[256];
+    __shared__ double s_p[256], s_q1[256], s_mu1[256], s_red[256], s_rcp[256], s_kp[256];
     __shared__ u32 s_valid[8];
     const int b = blockIdx.x, i = threadIdx.x;
     const double scale = 1.0 / (double)npix;
@@ -331,23 +341,56 @@ __global__ __launch_bounds__(256) void k_otsu_scan(const u32* __restrict__ hist,
         __syncthreads();
     }
     const double mu = s_red[0] * scale;
+    // (1) the running class weight: 256 dependent additions, one lane
     if (i == 0) {
-        double mu1 = 0, q1 = 0;
-        u32 vbits = 0;
+        double q1 = 0;
+#pragma unroll 8
         for (int k = 0; k < 256; k++) {
-            const double p_k = s_p[k];
-            mu1 *= q1;
-            q1 += p_k;
-            const double q2 = 1. - q1;
-            const bool ok = !(fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON);
-            if (ok) mu1 = (mu1 + k * p_k) / q1;
+            q1 += s_p[k];
             s_q1[k] = q1;
-            s_mu1[k] = mu1;
-            vbits |= ok ? 1u << (k & 31) : 0u;
-            if ((k & 31) == 31) {
-                s_valid[k >> 5] = vbits;
-                vbits = 0;
+        }
+    }
+    __syncthreads();
+    // (2) side by side for all levels: is the level skipped, the product k * p_k, and the part of the division by q1
+    // that does not depend on the numerator.  The division is the sequence the compiler emits for a double
+    // quotient (reciprocal estimate, two Newton steps, quotient, one correction); its scaling and fix-up steps
+    // are the identity here because q1 lies in [2^-23, 1) and the numerator in [0, 255].
+    const double q1_i = s_q1[i], q2_i = 1. - q1_i;
+    const bool ok_i = !(fmin(q1_i, q2_i) < FLT_EPSILON || fmax(q1_i, q2_i) > 1. - FLT_EPSILON);
+    {
+        const unsigned long long okm = __ballot(ok_i);
+        if ((i & 63) == 0) {
+            s_valid[(i >> 6) * 2] = (u32)okm;
+            s_valid[(i >> 6) * 2 + 1] = (u32)(okm >> 32);
+        }
+        double r = __builtin_amdgcn_rcp(q1_i);
+        r = __builtin_fma(r, __builtin_fma(-q1_i, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(-q1_i, r, 1.0), r);
+        s_rcp[i] = r;
+        s_kp[i] = i * s_p[i];
+    }
+    __syncthreads();
+    // (3) the class mean: the only chain that needs the previous level's result -- five dependent operations a level.
+    // q1 never falls, so the levels the scan does not skip form one interval [lo, hi]; before it mu1 is still 0
+    // (0 times anything finite), behind it nothing is looked at any more.
+    if (i == 0) {
+        int lo = 256, hi = -1;
+        for (int wd = 0; wd < 8; wd++) {
+            const u32 vb = s_valid[wd];
+            if (vb) {
+                if (lo == 256) lo = wd * 32 + __ffs(vb) - 1;
+                hi = wd * 32 + 31 - __clz(vb);
             }
+        }
+        double mu1 = 0, q1_prev = lo > 0 && lo < 256 ? s_q1[lo - 1] : 0.0;
+#pragma unroll 4
+        for (int k = lo; k <= hi; k++) {
+            const double q1 = s_q1[k], r = s_rcp[k], kp = s_kp[k];
+            const double num = mu1 * q1_prev + kp;
+            const double q0 = num * r;
+            mu1 = __builtin_fma(__builtin_fma(-q1, q0, num), r, q0);
+            q1_prev = q1;
+            s_mu1[k] = mu1;
         }
     }
     __syncthreads();
@@ -626,8 +669,22 @@ static int histogram_impl(Plane s, int width, int height, int batch, u32* hist, 
     IPA_HIP(hipMemsetAsync(hist, 0, (size_t)batch * 256 * sizeof(u32), st));
     int cpr = cdiv(width, 16);
     long long cpi = (long long)cpr * height;
-    unsigned gx = (unsigned)((cpi + 256 * 8 - 1) / (256 * 8));
-    unsigned cap = (unsigned)(1024 / (batch < 1024 ? batch : 1024));  // (few workgroups: every one ends with an atomic per non-empty bin on the image's 256 counters)
+    // 1024 threads per workgroup and at most 768 of them (three per CU): every workgroup ends with one global atomic
+    // per non-empty bin, so the same number of waves in fewer, larger workgroups costs less (one 16384 x 16384
+    // page: 1024 x 256 threads 85 us, 256 x 1024 82 us, 512 x 1024 71 us, 768 x 1024 70 us)
+    static int nt_env = -1;  // IPA_HIST_THREADS: 256 or 1024 (default) threads per workgroup (A/B)
+    if (nt_env < 0) {
+        const char* e = getenv("IPA_HIST_THREADS");
+        nt_env = e ? atoi(e) : 1024;
+    }
+    const int nt = nt_env == 256 ? 256 : 1024;
+    unsigned gx = (unsigned)((cpi + nt * 8 - 1) / (nt * 8));
+    static int cap_env = -1;  // IPA_HIST_CAP: workgroups per launch (A/B)
+    if (cap_env < 0) {
+        const char* e = getenv("IPA_HIST_CAP");
+        cap_env = e ? atoi(e) : 0;
+    }
+    unsigned cap = (unsigned)((cap_env > 0 ? cap_env : (nt == 1024 ? 768 : 1024)) / (batch < 768 ? batch : 768));  // (few workgroups: every one ends with an atomic per non-empty bin on the image's 256 counters)
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
@@ -643,7 +700,10 @@ static int histogram_impl(Plane s, int width, int height, int batch, u32* hist, 
             div_k = 28 + lb;
             div_m = (u32)((1ull << div_k) / (u32)cpr) + 1u;
         }
-        hipLaunchKernelGGL(k_hist, dim3(gx, nb), dim3(256), 0, st, sb, width, height, cpr, cpi, hist + (size_t)b0 * 256, div_m, div_k);
+        if (nt == 1024)
+            hipLaunchKernelGGL(k_hist<1024>, dim3(gx, nb), dim3(1024), 0, st, sb, width, height, cpr, cpi, hist + (size_t)b0 * 256, div_m, div_k);
+        else
+            hipLaunchKernelGGL(k_hist<256>, dim3(gx, nb), dim3(256), 0, st, sb, width, height, cpr, cpi, hist + (size_t)b0 * 256, div_m, div_k);
         IPA_LAUNCH_CHECK();
     }
     return IPA_OK;

@@ -447,6 +447,13 @@ __device__ __forceinline__ void vote_body(const VoteArgs& A, const Trig& T, cons
     }
     for (int i = tid; i < TG * span; i += NT) hist[i] = 0;
     __syncthreads();
+    // angles that vote from the points, as one scalar mask (a flag per angle kept in a vector condition cost two
+    // vector instructions per angle and trip to test)
+    u32 active = 0;
+#pragma unroll
+    for (int g = 0; g < TG; g++)
+        if (g < tg && !byrow[g]) active |= 1u << g;
+    active = (u32)__builtin_amdgcn_readfirstlane((int)active);
 
     if (NG == 0 || tid < NTV) {  // (wave-uniform) the waves that vote
     const u32 npts = min((u32)A.counts[b], A.cap);
@@ -501,16 +508,21 @@ __device__ __forceinline__ void vote_body(const VoteArgs& A, const Trig& T, cons
         const f2 x23 = {(float)(cur.z & 0xffffu), (float)(cur.w & 0xffffu)};
         const f2 y01 = {(float)(cur.x >> 16), (float)(cur.y >> 16)};
         const f2 y23 = {(float)(cur.z >> 16), (float)(cur.w >> 16)};
+        auto vote = [&](int g) {
+            const f2 r01 = (x01 * cg[g] + y01 * sg[g]) + magic;  // every op rounds on its own
+            const f2 r23 = (x23 * cg[g] + y23 * sg[g]) + magic;
+            atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.x) << 2) + k4[g])), 1u);
+            atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.y) << 2) + k4[g])), 1u);
+            atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.x) << 2) + k4[g])), 1u);
+            atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.y) << 2) + k4[g])), 1u);
+        };
+        if (active == (1u << TG) - 1u) {  // the usual case: all angles of the group, no branch per angle
 #pragma unroll
-        for (int g = 0; g < TG; g++) {
-            if (g < tg && !byrow[g]) {  // (wave-uniform)
-                const f2 r01 = (x01 * cg[g] + y01 * sg[g]) + magic;  // every op rounds on its own
-                const f2 r23 = (x23 * cg[g] + y23 * sg[g]) + magic;
-                atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.x) << 2) + k4[g])), 1u);
-                atomicAdd((u32*)(hb + (((u32)__float_as_int(r01.y) << 2) + k4[g])), 1u);
-                atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.x) << 2) + k4[g])), 1u);
-                atomicAdd((u32*)(hb + (((u32)__float_as_int(r23.y) << 2) + k4[g])), 1u);
-            }
+            for (int g = 0; g < TG; g++) vote(g);
+        } else {
+#pragma unroll
+            for (int g = 0; g < TG; g++)
+                if ((active >> g) & 1u) vote(g);
         }
     };
     if (trips) {

@@ -123,11 +123,11 @@ def threshold(src, thresh, maxval, type, dst=None):
     s = upload(src, 1)
     d = DevImage.empty(1, s.height, s.width, 1)
     if int(type) & THRESH_OTSU:
-        hist = torch.empty(256, dtype=torch.int32, device=s.t.device)
-        otsu = torch.zeros(1, dtype=torch.int32, device=s.t.device)
+        buf = torch.empty(257, dtype=torch.int32, device=s.t.device)  # histogram and the threshold (both written by the call)
+        hist, otsu = buf[:256], buf[256:]
         check(L.ipa_threshold_otsu_u8(s.ptr, s.pitch, s.stride, d.ptr, d.pitch, d.stride, s.width, s.height, 1,
                                       float(maxval), base, hist.data_ptr(), otsu.data_ptr(), stream_ptr()))
-        ret = float(otsu.item())
+        ret = float(otsu.item()) if s.width * s.height else 0.0  # (an empty image: nothing is written)
     else:
         check(L.ipa_threshold_u8(s.ptr, s.pitch, s.stride, d.ptr, d.pitch, d.stride, s.width, s.height, 1,
                                  float(thresh), float(maxval), base, stream_ptr()))
