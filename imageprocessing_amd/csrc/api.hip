@@ -109,11 +109,13 @@ IPA_EXPORT const char* ipa_last_error(void) { return g_err; }
 // vote_gray: 0 (default) = in the phased schedule the gray conversion of chunk c + 1 runs as a kernel of its own on the
 // helper stream beside a resident vote grid, 1 = it is done by spare waves of the vote kernel of chunk c (one launch),
 // 2 = as 1, with the opens of a chunk beside that chunk's vote instead of beside its Canny kernels.
+// hyst_rounds: Canny on images of more than 4096 tiles: region launches of the hysteresis queued before the kernel
+// that finishes what they left on the device (default 6; 1 leaves nearly everything to that kernel: tests).
 namespace {
-enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_CANNY_BANDS, OPT_CANNY_QUEUE, OPT_CANNY_WIDE, OPT_VOTE_GRAY, OPT_COUNT };
-const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks", "canny_bands", "canny_queue", "canny_wide", "vote_gray"};
-const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START", "IPA_CANNY_BANDS", "IPA_CANNY_QUEUE", "IPA_CANNY_WIDE", "IPA_VOTE_GRAY"};
-const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000, -1, 1, 0, 0};
+enum { OPT_PIPELINE = 0, OPT_OVERLAP, OPT_PHASED, OPT_HEAD_START, OPT_CANNY_BANDS, OPT_CANNY_QUEUE, OPT_CANNY_WIDE, OPT_VOTE_GRAY, OPT_HYST_ROUNDS, OPT_COUNT };
+const char* const g_opt_name[OPT_COUNT] = {"pipeline_chunks", "overlap", "phased", "head_start_ticks", "canny_bands", "canny_queue", "canny_wide", "vote_gray", "hyst_rounds"};
+const char* const g_opt_env[OPT_COUNT] = {"IPA_PIPELINE", "IPA_OVERLAP", "IPA_PHASED", "IPA_HEAD_START", "IPA_CANNY_BANDS", "IPA_CANNY_QUEUE", "IPA_CANNY_WIDE", "IPA_VOTE_GRAY", "IPA_HYST_ROUNDS"};
+const int g_opt_default[OPT_COUNT] = {-1, 1, 1, 3000, -1, 1, 0, 0, 6};
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
 void options_init()
@@ -135,6 +137,7 @@ int option(int which)
 int option_canny_bands() { return option(OPT_CANNY_BANDS); }
 int option_canny_queue() { return option(OPT_CANNY_QUEUE); }
 int option_canny_wide() { return option(OPT_CANNY_WIDE); }
+int option_hyst_rounds() { return option(OPT_HYST_ROUNDS); }
 
 IPA_EXPORT int ipa_set_option(const char* name, int value)
 {

@@ -1092,24 +1092,19 @@ __device__ __forceinline__ TileBits load_bits64(const u8* p, int nvalid)
 // atomic ORs; if the rim of the tile changed, the neighbouring tiles with WEAK pixels go on
 // the next round's list.  Rounds are separated by a workgroup barrier (which also drains
 // the stores) and an L1 invalidate, so a round sees everything the previous one wrote.
+// One region (rx, ry) of image b, by the whole workgroup.  any_mark (LDS, or nullptr): set when a tile of another
+// region was marked for a revisit.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
-                                                           int rt_x, int rt_y, int regions_x, int regions_y,
-                                                           CannyWs W, PointSink sink, int seed_pending, int round_no)
+__device__ __forceinline__ void hyst_region(Plane dst, int w, int h, int tiles_x, int tiles_y, int rt_x, int rt_y, int rx,
+                                            int ry, int b, const CannyWs& W, const PointSink& sink, int seed_pending,
+                                            int round_no, u32* any_mark)
 {
-    // Launch `round_no` of a sequence over the regions of huge images: nothing is left to do when the
-    // launch before it did not ask for another one (it would have raised *again to round_no).
-    if (round_no > 0 && *(volatile const u32*)W.again < (u32)round_no) return;
     __shared__ u16 s_list[2][HT_MAX_TILES];
     __shared__ u32 s_inq[HT_MAX_TILES / 32];
     __shared__ u32 s_flag[HT_MAX_TILES / 32];
     __shared__ u32 s_cnt[2];
     __shared__ u32 s_cursor;
     const int tid = threadIdx.x, lane = tid & 63;
-    int blk = blockIdx.x;
-    const int rx = blk % regions_x;
-    blk /= regions_x;
-    const int ry = blk % regions_y, b = blk / regions_y;
     const int tx_base = rx * rt_x, ty_base = ry * rt_y;
     const int nx_t = min(rt_x, tiles_x - tx_base), ny_t = min(rt_y, tiles_y - ty_base);
 
@@ -1280,6 +1275,7 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
                         // belongs to another workgroup's region: left to a later launch
                         if (W.pending) W.pending[((size_t)b * tiles_y + gty) * tiles_x + gtx] = 1;
                         if (round_no >= 0) atomicMax(W.again, (u32)round_no + 1u);
+                        if (any_mark) *any_mark = 1u;
                     }
                 }
             }
@@ -1293,6 +1289,70 @@ __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before re-reading tiles
         __syncthreads();
         cur = nxt;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
+                                                           int rt_x, int rt_y, int regions_x, int regions_y,
+                                                           CannyWs W, PointSink sink, int seed_pending, int round_no)
+{
+    // Launch `round_no` of a sequence over the regions of huge images: nothing is left to do when the
+    // launch before it did not ask for another one (it would have raised *again to round_no).
+    if (round_no > 0 && *(volatile const u32*)W.again < (u32)round_no) return;
+    int blk = blockIdx.x;
+    const int rx = blk % regions_x;
+    blk /= regions_x;
+    const int ry = blk % regions_y, b = blk / regions_y;
+    hyst_region<NT>(dst, w, h, tiles_x, tiles_y, rt_x, rt_y, rx, ry, b, W, sink, seed_pending, round_no, nullptr);
+}
+
+// What the region launches of a huge image left undone after their fixed number of rounds, to the fixed point and
+// without the host: one workgroup per image sweeps over the image's regions, works on those that hold marked
+// tiles (marks of the previous sweep or of the last region launch), collects the marks of this sweep in the other
+// set, and stops after a sweep that marked nothing.  Returns at once when the last region launch asked for nothing.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hyst_drain(Plane dst, int w, int h, int tiles_x, int tiles_y, int rt_x, int rt_y,
+                                                   int regions_x, int regions_y, CannyWs W, PointSink sink, int first_round)
+{
+    if (*(volatile const u32*)W.again < (u32)first_round) return;
+    __shared__ u32 s_any, s_has;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    u8 *in = (u8*)W.pending_in, *out = W.pending;
+    const size_t t0 = (size_t)b * tiles_y * tiles_x;
+    const int nt = tiles_x * tiles_y;
+    for (int sweep = 0; sweep < (1 << 24); sweep++) {
+        for (int i = tid; i < nt; i += NT) out[t0 + i] = 0;
+        if (tid == 0) s_any = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int ry = 0; ry < regions_y; ry++)
+            for (int rx = 0; rx < regions_x; rx++) {
+                const int tx_base = rx * rt_x, ty_base = ry * rt_y;
+                const int nx_t = min(rt_x, tiles_x - tx_base), ny_t = min(rt_y, tiles_y - ty_base);
+                if (tid == 0) s_has = 0;
+                __syncthreads();
+                for (int t = tid; t < nx_t * ny_t; t += NT) {
+                    const size_t gt = t0 + (size_t)(ty_base + t / nx_t) * tiles_x + tx_base + t % nx_t;
+                    if (in[gt] && W.has_weak[gt]) s_has = 1u;
+                }
+                __syncthreads();
+                if (s_has) {  // (uniform over the workgroup)
+                    CannyWs Wr = W;
+                    Wr.pending = out;
+                    Wr.pending_in = in;
+                    hyst_region<NT>(dst, w, h, tiles_x, tiles_y, rt_x, rt_y, rx, ry, b, Wr, sink, 1, -1, &s_any);
+                }
+                __syncthreads();
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (!s_any) break;  // (uniform: read after the barrier)
+        __syncthreads();
+        u8* const tmp = in;
+        in = out;
+        out = tmp;
     }
 }
 
@@ -1609,32 +1669,42 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     const bool multi = regions_x * regions_y > 1;
     // Several regions per image: launch r starts from the tiles launch r-1 marked across region borders
     // (launch 0 from every tile with WEAK pixels) and marks the tiles it changes across borders in turn;
-    // the two sets of marks alternate.  Launches are queued four at a time -- one that has nothing to
-    // do returns at once -- and the host reads the counter once per group.
+    // the two sets of marks alternate.  A fixed number of launches is queued -- one that has nothing to do
+    // returns at once -- and a last kernel (one workgroup per image) takes whatever they left to the fixed
+    // point on the device: the host never waits for the stream and nothing is copied back.
     u8* const pend[2] = {pending, pending + align_up(ntiles, 256)};
-    if (multi) IPA_HIP(hipMemsetAsync(W.again, 0, 16, st));
-    for (int r = 0; r < 100000; r++) {
-        CannyWs Wr = W;
-        if (multi) {
+    if (!multi) {
+        if (blocks < 1024)
+            hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink, 0, -1);
+        else
+            hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
+                               tiles_y, rt_x, rt_y, regions_x, regions_y, W, sink, 0, -1);
+        IPA_LAUNCH_CHECK();
+    } else {
+        IPA_HIP(hipMemsetAsync(W.again, 0, 16, st));
+        int rounds = option_hyst_rounds();  // region launches before the drain kernel (run-time option hyst_rounds)
+        rounds = rounds < 1 ? 1 : (rounds > 64 ? 64 : rounds);
+        for (int r = 0; r < rounds; r++) {
+            CannyWs Wr = W;
             Wr.pending = pend[r & 1];
             Wr.pending_in = pend[(r + 1) & 1];
             IPA_HIP(hipMemsetAsync(pend[r & 1], 0, align_up(ntiles, 256), st));
+            // few workgroups (small batches, single images): twice the waves per workgroup
+            if (blocks < 1024)
+                hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
+                                   tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, r > 0 ? 1 : 0, r);
+            else
+                hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
+                                   tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, r > 0 ? 1 : 0, r);
+            IPA_LAUNCH_CHECK();
         }
-        const int seed = multi && r > 0 ? 1 : 0, rn = multi ? r : -1;
-        // few workgroups (small batches, single images): twice the waves per workgroup
-        if (blocks < 1024)
-            hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
-                               tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, seed, rn);
-        else
-            hipLaunchKernelGGL(k_hyst_tiles<HT_THREADS>, dim3((unsigned)blocks), dim3(HT_THREADS), 0, st, dst, w, h, tiles_x,
-                               tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, seed, rn);
+        CannyWs Wd = W;
+        Wd.pending = pend[rounds & 1];           // (cleared by the kernel itself)
+        Wd.pending_in = pend[(rounds + 1) & 1];  // the marks of the last region launch
+        hipLaunchKernelGGL(k_hyst_drain<2 * HT_THREADS>, dim3((unsigned)batch), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
+                           tiles_y, rt_x, rt_y, regions_x, regions_y, Wd, sink, rounds);
         IPA_LAUNCH_CHECK();
-        if (!multi) break;
-        if ((r & 3) != 3) continue;
-        u32 again = 0;  // (pageable destination: the runtime stages the copy, nothing is allocated here)
-        IPA_HIP(hipMemcpyAsync(&again, W.again, 4, hipMemcpyDeviceToHost, st));
-        IPA_HIP(hipStreamSynchronize(st));
-        if (again <= (u32)r) break;  // launch r did not ask for launch r + 1
     }
     launch_hyst_final(dst, w, h, tiles_x, tiles_y, ntiles, (const u8*)W.has_weak, st);
     IPA_LAUNCH_CHECK();

@@ -210,6 +210,7 @@ size_t canny_ws_bytes(int w, int h, int batch);
 int option_canny_bands();
 int option_canny_queue();
 int option_canny_wide();
+int option_hyst_rounds();
 
 // flags_cleared: the area canny_flag_area() names has been zeroed by the caller (on the same stream)
 // nms_done: the codes (0 / WEAK / 255) and the tile flags are already in place (launch_canny_wide with a BGR source)

@@ -80,6 +80,8 @@ size_t ipa_pitch_for(size_t row_bytes);
  *                                        conversion inside ipa_front_end_u8); -1 = that kernel for large launches
  *   "vote_gray"        [IPA_VOTE_GRAY]   0 = default; 1 = in the phased schedule the gray conversion of the next
  *                                        chunk runs on spare waves of the vote kernel; 2 = as 1, opens one phase later
+ *   "hyst_rounds"      [IPA_HYST_ROUNDS] Canny on images of more than 4096 tiles: region launches of the hysteresis
+ *                                        before the kernel that finishes on the device (default 6)
  * Results do not depend on any of them.  Settings apply to the calls that follow, from any thread. */
 int ipa_set_option(const char* name, int value);
 int ipa_get_option(const char* name, int* value);
@@ -242,12 +244,13 @@ int ipa_binary_check_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
 /* cv2.Canny(gray, t1, t2, apertureSize=3, L2gradient=False): lineDetection.py:9;
  * "New Version/comparison.py":13; "Version4 with Chatgpt/contour_detection.py":61;
  * newVersion3/detectHorizontalVerticalLines.py:61; "New Version/detectArrow.py":8.
- * Hysteresis runs to its fixed point without any host interaction for images of
- * at most 4096 tiles of 128x32 pixels (one workgroup per image; for batches of up
- * to 48 images a first launch works on small regions side by side and a second one
- * finishes what crosses their borders); larger images are resolved region by
- * region in launches queued four at a time, and the call then synchronises `stream`
- * once per group to learn whether another group is needed. */
+ * Hysteresis runs to its fixed point on the device, without any host interaction, for
+ * every image size: one workgroup per image for images of at most 4096 tiles of 128x32
+ * pixels (for batches of up to 48 images a first launch works on small regions side by
+ * side and a second one finishes what crosses their borders); larger images are resolved
+ * region by region in a fixed number of launches (run-time option "hyst_rounds"), after
+ * which one workgroup per image follows whatever is left across region borders.  The call
+ * never synchronises `stream` and copies nothing to the host. */
 size_t ipa_canny_workspace_bytes(int width, int height, int batch);
 int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
                  uint8_t* dst, size_t dst_pitch, size_t dst_stride,
@@ -265,9 +268,8 @@ int ipa_canny_u8(const uint8_t* src, size_t src_pitch, size_t src_stride,
  * ipa_canny_static_max_bytes(): more than about 174 000 tiles of 128x32 pixels, e.g. 85
  * images of 3840x2160) are refused with IPA_ERR_WORKSPACE.  The device of `stream` must be
  * the current device (checked: IPA_ERR_ARG otherwise).  The call neither synchronises nor
- * copies to the host - and is therefore safe under stream capture - only for images of at most
- * 4096 tiles (e.g. 4096 x 4096 pixels); larger images make the hysteresis read one counter back per
- * group of launches, as described for ipa_canny_u8.  All calls on one GPU share the array: calls that overlap in time on
+ * copies to the host, whatever the image size, and is therefore safe under stream capture.
+ * All calls on one GPU share the array: calls that overlap in time on
  * one GPU (different streams or threads) race and must be serialised by the caller. */
 #define IPA_CANNY_STATIC_SCRATCH_BYTES ((size_t)512 * 1024)
 size_t ipa_canny_static_max_bytes(void);

@@ -103,9 +103,9 @@ def _weak_serpentine(h, w):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("h,w", [(4352, 4352), (2100, 8400)])
 def test_canny_hysteresis_over_many_regions_of_a_huge_image(h, w):
-    # more than 4096 tiles of 128x32: hysteresis runs region by region (16x16 tiles), several launches
-    # queued at a time; a weak curve seeded at one end crosses every region border many times and needs
-    # dozens of launches to be followed to its other end
+    # more than 4096 tiles of 128x32: hysteresis runs region by region (8x8 tiles) for a fixed number of launches,
+    # then one workgroup per image finishes on the device; a weak curve seeded at one end crosses every region
+    # border many times, so nearly all of it is left to that last kernel
     import imageprocessing_amd as cv2
 
     assert (-(-w // 128)) * (-(-h // 32)) > 4096
@@ -118,4 +118,14 @@ def test_canny_hysteresis_over_many_regions_of_a_huge_image(h, w):
     # the same through the fused pass (gray as BGR), and upside down
     pad = np.stack([g[::-1, ::-1]] * 3, axis=-1)
     r = cv2.front_end(np.ascontiguousarray(pad), hough=False)
-    assert np.array_equal(r.edges, fr.canny(np.ascontiguousarray(g[::-1, ::-1]), 50, 150))
+    want_flipped = fr.canny(np.ascontiguousarray(g[::-1, ::-1]), 50, 150)
+    assert np.array_equal(r.edges, want_flipped)
+    # two images in one call (a finishing workgroup each), with one region launch and with many before it
+    both = np.stack([np.stack([g] * 3, axis=-1), pad])
+    for rounds in (1, 40):
+        cv2.set_option("hyst_rounds", rounds)
+        try:
+            rb = cv2.front_end_batch(both, hough=False)
+        finally:
+            cv2.set_option("hyst_rounds", 6)
+        assert np.array_equal(rb.edges[0], want) and np.array_equal(rb.edges[1], want_flipped), rounds

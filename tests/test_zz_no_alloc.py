@@ -68,3 +68,17 @@ def test_static_scratch_canny_refuses_what_does_not_fit():
     # empty input: nothing to do
     assert L.ipa_canny_static_u8(one.ptr, one.pitch, one.stride, one.ptr, one.pitch, one.stride, 0, 0, 0, 50.0, 150.0,
                                  stream_ptr()) == 0
+
+
+def test_static_scratch_canny_on_an_image_of_more_than_4096_tiles():
+    # the hysteresis of such images runs region by region and is finished by a device kernel: the call still
+    # neither allocates nor waits for the stream
+    from imageprocessing_amd import _native
+    from oracle import frontref as fr
+
+    L = _native.lib()
+    g = fr.bgr2gray(uml_like(901, 2176, 8192, noise=6))
+    assert (8192 // 128) * (2176 // 32) > 4096
+    a, b = _both(L, g, 50, 150)
+    assert torch.equal(a, b)
+    assert np.array_equal(b[0].cpu().numpy(), fr.canny(g, 50, 150))
