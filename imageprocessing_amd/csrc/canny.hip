@@ -1206,6 +1206,14 @@ __device__ __forceinline__ void hyst_region(Plane dst, int w, int h, int tiles_x
             u64 S = me.S;
             if (__any(me.W != 0)) {
                 for (;;) {
+                    const u64 S_in = S;
+                    {   // runs of passable pixels (WEAK or edge) along the row are filled from their edge pixels in one
+                        // step, upwards by the carries of M + S, downwards the same on the reversed words
+                        const u64 M = me.W | S;
+                        S |= M & ((M + S) ^ M ^ S);
+                        const u64 Mr = __brevll(M), Sr = __brevll(S);
+                        S |= __brevll(Mr & ((Mr + Sr) ^ Mr ^ Sr));
+                    }
                     // the pixel next to this lane's inner end belongs to the other half of the row
                     const u32 pS = (u32)__shfl_xor((int)(hf ? (u32)(S & 1ull) : (u32)(S >> 63)), 32);
                     const u64 lin = hf ? (u64)pS : (u64)side;
@@ -1219,7 +1227,7 @@ __device__ __forceinline__ void hyst_region(Plane dst, int w, int h, int tiles_x
                     if (r == 0) up = ringH;
                     if (r == TH - 1) dn = ringH;
                     const u64 Sn = S | (me.W & (H | up | dn));
-                    const bool ch = Sn != S;
+                    const bool ch = Sn != S_in;
                     S = Sn;
                     if (!__any(ch)) break;
                 }
