@@ -536,6 +536,11 @@ def main():
             ipa.set_option("phased", phased)
             ipa.set_option("canny_bands", int(rng.choice([-1, 16, 64, 64])))
             ipa.set_option("canny_queue", int(rng.random() < 0.8))
+            # the kernel variants behind options (whole-line Canny kernel, gray conversion on spare vote waves) and
+            # the number of hysteresis region launches before the finishing kernel
+            ipa.set_option("canny_wide", int(rng.choice([0, 0, 4, 8, -1])))
+            ipa.set_option("vote_gray", int(rng.choice([0, 0, 1, 2])))
+            ipa.set_option("hyst_rounds", int(rng.choice([6, 6, 1, 2])))
             r = ipa.front_end_batch(imgs, thresh_val=t, vert_len=vl, horiz_len=hl, iterations=it, canny=(lo, hi),
                                     blur=blur, hough=hough, edges=edges)
             acc = r.accum.cpu().numpy() if r.accum is not None else None
