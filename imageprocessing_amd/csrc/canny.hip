@@ -1549,10 +1549,9 @@ size_t canny_ws_bytes(int w, int h, int batch)
     return 3 * align_up(ntiles, 256) + 512;
 }
 
-// Enqueues the whole detector.  Images of up to HT_MAX_TILES tiles (e.g. 4K) are
-// resolved by one workgroup each with no host interaction; larger images are cut
-// into regions and the stream is synchronised to learn whether a further
-// hysteresis launch is needed.
+// Enqueues the whole detector; nothing here waits for the stream.  Images of up to HT_MAX_TILES tiles
+// (e.g. 4K) are resolved by one workgroup each; larger images are cut into regions, worked on in a
+// fixed number of launches and finished by one workgroup per image (k_hyst_drain).
 // The part of the workspace run_canny wants zeroed before its first kernel (tile flags and the first set of marks).
 void canny_flag_area(int w, int h, int batch, void* ws, u32** p, u32* dwords)
 {
@@ -1579,7 +1578,7 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
     // Few images of at most HT_MAX_TILES tiles: one workgroup per image would leave the chip idle, so a
     // first launch works on small regions side by side and marks the tiles across region borders that
     // would have to be revisited; a second launch (one workgroup per image, started from the marked
-    // tiles only) then runs to the fixed point.  No host round trip, unlike the loop for huge images.
+    // tiles only) then runs to the fixed point.
     const int tiles_x0 = cdiv(w, TW), tiles_y0 = cdiv(h, TH);
     static int side_env = -2;  // IPA_HYST_SMALL_SIDE: region side in tiles of the first launch (0 = off; default: by batch)
     if (side_env == -2) {

@@ -373,8 +373,8 @@ int ipa_hough_lines_p_u8(const uint8_t* src, size_t src_pitch, size_t src_stride
  *   accum  = vote accumulator of HoughLines(edges, 1, pi/180, .)   (skipped if NULL;
  *            seg_max as for ipa_hough_accum_u8, may be NULL)
  * The five output planes share one pitch/stride.  edges = NULL skips Canny (the parsers
- * only need the first four planes); accum must then be NULL as well.  Synchronises
- * `stream` only where ipa_canny_u8 does.  Batches of about 1.5 gigapixels or more run as chunks
+ * only need the first four planes); accum must then be NULL as well.  Never synchronises
+ * `stream`.  Batches of about 1.5 gigapixels or more run as chunks
  * whose stages overlap on helper streams of the library (the vote of one chunk beside
  * the binarisation of the next, the opens beside Canny); all of it is joined back into
  * `stream` before the call returns, so the caller sees ordinary stream order. */
