@@ -1300,6 +1300,201 @@ __device__ __forceinline__ void hyst_region(Plane dst, int w, int h, int tiles_x
     }
 }
 
+
+// A region of at most 8 x 8 tiles (1024 x 256 pixels) with its state in LDS: the edge and WEAK bits of the whole region
+// (two bit planes, 64 pixels per word, the edge plane with a ring of one pixel around the region) are built once from
+// the bytes, the worklist rounds of hyst_region then run on LDS alone -- a round costs a barrier and a few LDS round
+// trips instead of loads, atomics and a cache invalidate in global memory, which is what a weak chain that winds
+// through the tiles of a region pays per tile -- and the promoted pixels are written back at the end.  The ring is what
+// the neighbouring regions held when the launch started; tiles across the border are marked for the next launch as in
+// hyst_region.
+constexpr int HL_T = 8;                      // tiles per region side
+constexpr int HL_ROWS = HL_T * TH;           // 256 rows
+constexpr int HL_WORDS = HL_T * (TW / 64);   // 16 words per row
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hyst_tiles_lds(Plane dst, int w, int h, int tiles_x, int tiles_y, int regions_x,
+                                                       int regions_y, CannyWs W, int seed_pending, int round_no)
+{
+    if (round_no > 0 && *(volatile const u32*)W.again < (u32)round_no) return;
+    __shared__ u64 sS[HL_ROWS + 2][HL_WORDS + 2];  // row -1 .. 256, word -1 .. 16 (index + 1)
+    __shared__ u64 sW[HL_ROWS][HL_WORDS];
+    __shared__ u16 s_list[2][HL_T * HL_T];
+    __shared__ u32 s_inq[2], s_flag[2], s_cnt[2], s_cursor;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    int blk = blockIdx.x;
+    const int rx = blk % regions_x;
+    blk /= regions_x;
+    const int ry = blk % regions_y, b = blk / regions_y;
+    const int tx_base = rx * HL_T, ty_base = ry * HL_T;
+    const int nx_t = min(HL_T, tiles_x - tx_base), ny_t = min(HL_T, tiles_y - ty_base);
+    const int ntile = nx_t * ny_t;
+    const int X0 = tx_base * TW, Y0 = ty_base * TH;  // first pixel of the region
+
+    if (tid < 2) {
+        s_inq[tid] = 0;
+        s_flag[tid] = 0;
+        s_cnt[tid] = 0;
+    }
+    if (tid == 0) s_cursor = 0;
+    __syncthreads();
+    // worklist of the first round, and is there anything to do at all
+    for (int t = tid; t < ntile; t += NT) {
+        const int lx = t % nx_t, ly = t / nx_t;
+        const size_t gt = ((size_t)b * tiles_y + ty_base + ly) * tiles_x + tx_base + lx;
+        if (W.has_weak[gt]) {
+            atomicOr(&s_flag[t >> 5], 1u << (t & 31));
+            if (!seed_pending || W.pending_in[gt]) {
+                const u32 pos = atomicAdd(&s_cnt[0], 1u);
+                s_list[0][pos] = (u16)t;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_cnt[0] == 0) return;  // (uniform)
+
+    // ---- build the bit planes -------------------------------------------------------------------------
+    for (int i = tid; i < (HL_ROWS + 2) * (HL_WORDS + 2); i += NT) (&sS[0][0])[i] = 0;
+    for (int i = tid; i < HL_ROWS * HL_WORDS; i += NT) (&sW[0][0])[i] = 0;
+    __syncthreads();
+    const int r = lane & 31, hf = lane >> 5;  // lane = (64-pixel half, row) of a tile
+    for (int t = wave; t < ntile; t += NW) {
+        const int lx = t % nx_t, ly = t / nx_t;
+        const int iy = Y0 + ly * TH + r, xh = X0 + lx * TW + 64 * hf;
+        if (iy < h && w - xh > 0) {
+            const TileBits me = bits_of_raw64(load_raw64(dst.row(b, iy) + xh, w - xh), w - xh);
+            sS[ly * TH + r + 1][lx * 2 + hf + 1] = me.S;
+            sW[ly * TH + r][lx * 2 + hf] = me.W;
+        }
+    }
+    // the ring: the row above and the row below the region (a word per lane), the columns left and right of it
+    {
+        const int nwords = nx_t * 2, nrows = ny_t * TH;
+        for (int i = tid; i < 2 * nwords; i += NT) {
+            const int below = i >= nwords, wd = below ? i - nwords : i;
+            const int iy = below ? Y0 + nrows : Y0 - 1, xh = X0 + wd * 64;
+            if (iy >= 0 && iy < h && w - xh > 0)
+                sS[below ? nrows + 1 : 0][wd + 1] = bits_of_raw64(load_raw64(dst.row(b, iy) + xh, w - xh), w - xh).S;
+        }
+        for (int i = tid; i < 2 * (nrows + 2); i += NT) {
+            const int right = i >= nrows + 2, rr = (right ? i - (nrows + 2) : i) - 1;  // row -1 .. nrows
+            const int iy = Y0 + rr, ix = right ? X0 + nwords * 64 : X0 - 1;
+            if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+                const u64 bit = (u64)(dst.row(b, iy)[ix] >> 7);
+                sS[rr + 1][right ? nwords + 1 : 0] = right ? bit : bit << 63;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- rounds on LDS ----------------------------------------------------------------------------------
+    int cur = 0;
+    for (int round = 0; round < (1 << 24); round++) {
+        const u32 n = s_cnt[cur];
+        if (n == 0) break;
+        const int nxt = cur ^ 1;
+        for (;;) {
+            u32 i = 0;
+            if (lane == 0) i = atomicAdd(&s_cursor, 1u);
+            i = (u32)__builtin_amdgcn_readfirstlane((int)i);
+            if (i >= n) break;
+            const int t = (int)s_list[cur][i];
+            const int lx = t % nx_t, ly = t / nx_t;
+            const int row = ly * TH + r + 1, word = lx * 2 + hf + 1;  // (indices into sS)
+            const u64 S0 = sS[row][word], Wm = sW[row - 1][word - 1];
+            // the edge bit just outside this lane's outer end of the row
+            const u32 side = hf ? (u32)(sS[row][word + 1] & 1ull) : (u32)(sS[row][word - 1] >> 63);
+            u64 ringS = 0;
+            u32 ring_side = 0;
+            if (r == 0 || r == TH - 1) {
+                const int rr = r == 0 ? row - 1 : row + 1;
+                ringS = sS[rr][word];
+                ring_side = hf ? (u32)(sS[rr][word + 1] & 1ull) : (u32)(sS[rr][word - 1] >> 63);
+            }
+            u64 ringH;
+            {
+                const u32 pr = (u32)__shfl_xor((int)(hf ? (u32)(ringS & 1ull) : (u32)(ringS >> 63)), 32);
+                const u64 lin = hf ? (u64)pr : (u64)ring_side;
+                const u64 rin = hf ? (u64)ring_side : (u64)pr;
+                ringH = ringS | (ringS << 1) | (ringS >> 1) | lin | (rin << 63);
+            }
+            u64 S = S0;
+            if (__any(Wm != 0)) {
+                for (;;) {
+                    const u64 S_in = S;
+                    {
+                        const u64 M = Wm | S;
+                        S |= M & ((M + S) ^ M ^ S);
+                        const u64 Mr = __brevll(M), Sr = __brevll(S);
+                        S |= __brevll(Mr & ((Mr + Sr) ^ Mr ^ Sr));
+                    }
+                    const u32 pS = (u32)__shfl_xor((int)(hf ? (u32)(S & 1ull) : (u32)(S >> 63)), 32);
+                    const u64 lin = hf ? (u64)pS : (u64)side;
+                    const u64 rin = hf ? (u64)side : (u64)pS;
+                    const u64 H = S | (S << 1) | (S >> 1) | lin | (rin << 63);
+                    const u32 Hl = (u32)H, Hh = (u32)(H >> 32);
+                    u64 up = (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)Hl, 0x138, 0xf, 0xf, false) |
+                             ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)Hh, 0x138, 0xf, 0xf, false) << 32);
+                    u64 dn = (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)Hl, 0x130, 0xf, 0xf, false) |
+                             ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)Hh, 0x130, 0xf, 0xf, false) << 32);
+                    if (r == 0) up = ringH;
+                    if (r == TH - 1) dn = ringH;
+                    const u64 Sn = S | (Wm & (H | up | dn));
+                    const bool ch = Sn != S_in;
+                    S = Sn;
+                    if (!__any(ch)) break;
+                }
+            }
+            const u64 prom = S & ~S0;
+            if (prom) sS[row][word] = S;
+            const bool rim = prom && (r == 0 || r == TH - 1 || (hf == 0 && (prom & 1ull)) || (hf == 1 && (prom >> 63)));
+            if (__any(rim) && lane < 9 && lane != 4) {
+                const int nlx = lx + (lane % 3) - 1, nly = ly + (lane / 3) - 1;
+                const int gtx = tx_base + nlx, gty = ty_base + nly;
+                if (gtx >= 0 && gtx < tiles_x && gty >= 0 && gty < tiles_y) {
+                    if (nlx >= 0 && nlx < nx_t && nly >= 0 && nly < ny_t) {
+                        const int nt = nly * nx_t + nlx;
+                        if ((s_flag[nt >> 5] >> (nt & 31)) & 1u) {
+                            const u32 old = atomicOr(&s_inq[nt >> 5], 1u << (nt & 31));
+                            if (!((old >> (nt & 31)) & 1u)) {
+                                const u32 pos = atomicAdd(&s_cnt[nxt], 1u);
+                                s_list[nxt][pos] = (u16)nt;
+                            }
+                        }
+                    } else if (W.has_weak[((size_t)b * tiles_y + gty) * tiles_x + gtx]) {
+                        W.pending[((size_t)b * tiles_y + gty) * tiles_x + gtx] = 1;
+                        atomicMax(W.again, (u32)round_no + 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_cnt[cur] = 0;
+            s_cursor = 0;
+        }
+        if (tid < 2) s_inq[tid] = 0;
+        __syncthreads();
+        cur = nxt;
+    }
+
+    // ---- promoted pixels back to the bytes --------------------------------------------------------------
+    for (int t = wave; t < ntile; t += NW) {
+        if (!((s_flag[t >> 5] >> (t & 31)) & 1u)) continue;  // (uniform over the wave)
+        const int lx = t % nx_t, ly = t / nx_t;
+        const int iy = Y0 + ly * TH + r, xh = X0 + lx * TW + 64 * hf;
+        const u64 prom = sS[ly * TH + r + 1][lx * 2 + hf + 1] & sW[ly * TH + r][lx * 2 + hf];
+        if (prom) {
+            u8* row = dst.row(b, iy) + xh;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const u32 nib = (u32)(prom >> (4 * q)) & 0xfu;
+                if (nib) atomicOr((u32*)(row + 4 * q), ((nib * 0x00204081u) & 0x01010101u) * 0xffu);
+            }
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hyst_tiles(Plane dst, int w, int h, int tiles_x, int tiles_y,
                                                            int rt_x, int rt_y, int regions_x, int regions_y,
@@ -1692,13 +1887,24 @@ int run_canny(Plane src, Plane dst, int w, int h, int batch, int low, int high, 
         IPA_HIP(hipMemsetAsync(W.again, 0, 16, st));
         int rounds = option_hyst_rounds();  // region launches before the drain kernel (run-time option hyst_rounds)
         rounds = rounds < 1 ? 1 : (rounds > 64 ? 64 : rounds);
+        // regions of 8 x 8 tiles keep their state in LDS (not with the fused edge-pixel list; IPA_HYST_LDS=0: A/B)
+        static int lds_env = -1;
+        if (lds_env < 0) {
+            const char* e = getenv("IPA_HYST_LDS");
+            lds_env = e ? atoi(e) : 1;
+        }
+        const bool lds_regions = lds_env != 0 && !sink.pts && rt_x <= HL_T && rt_y <= HL_T && (rt_x == HL_T || regions_x == 1) &&
+                                 (rt_y == HL_T || regions_y == 1);
         for (int r = 0; r < rounds; r++) {
             CannyWs Wr = W;
             Wr.pending = pend[r & 1];
             Wr.pending_in = pend[(r + 1) & 1];
             IPA_HIP(hipMemsetAsync(pend[r & 1], 0, align_up(ntiles, 256), st));
             // few workgroups (small batches, single images): twice the waves per workgroup
-            if (blocks < 1024)
+            if (lds_regions)
+                hipLaunchKernelGGL(k_hyst_tiles_lds<1024>, dim3((unsigned)blocks), dim3(1024), 0, st, dst, w, h, tiles_x, tiles_y,
+                                   regions_x, regions_y, Wr, r > 0 ? 1 : 0, r);
+            else if (blocks < 1024)
                 hipLaunchKernelGGL(k_hyst_tiles<2 * HT_THREADS>, dim3((unsigned)blocks), dim3(2 * HT_THREADS), 0, st, dst, w, h, tiles_x,
                                    tiles_y, rt_x, rt_y, regions_x, regions_y, Wr, sink, r > 0 ? 1 : 0, r);
             else

@@ -36,12 +36,21 @@ def main():
     write = per_kernel(os.path.join(root, "write"), "WRITE_SIZE")
     stage = collections.defaultdict(float)
     rows = []
+    # passes of the front-end in the run = launches of the gray kernel (one per pass); a kernel that is launched
+    # several times per pass (the hysteresis rounds of a huge image) counts with all of them
+    def passes(vals):
+        for g in ("k_bgr2gray_flat", "k_bgr2gray", "k_canny_wide"):
+            if vals.get(g):
+                return len(vals[g])
+        return None
     for k in sorted(set(fetch) | set(write)):
         if k not in STAGE_OF:
             continue
-        # the first launch of each kernel belongs to the planning run; all launches do the same work
-        f = 2.0 * 1024 * (sum(fetch[k]) / len(fetch[k])) if fetch.get(k) else 0.0
-        w = 1024.0 * (sum(write[k]) / len(write[k])) if write.get(k) else 0.0
+        # (the first pass is the planning run; all passes do the same work)
+        nf = min(passes(fetch) or 1 << 30, len(fetch.get(k) or [1]))  # (a kernel with fewer launches than passes: per launch)
+        nw = min(passes(write) or 1 << 30, len(write.get(k) or [1]))
+        f = 2.0 * 1024 * (sum(fetch[k]) / nf) if fetch.get(k) else 0.0
+        w = 1024.0 * (sum(write[k]) / nw) if write.get(k) else 0.0
         stage[STAGE_OF[k]] += f + w
         rows.append((k, len(fetch.get(k, [])), f, w))
     data = {}
@@ -49,9 +58,10 @@ def main():
         data = json.load(open(out))
     data[key] = {s: round(v) for s, v in stage.items()}
     valu = collections.defaultdict(float)
-    for k, v in per_kernel(os.path.join(root, "sq2"), "SQ_INSTS_VALU").items():
+    vals = per_kernel(os.path.join(root, "sq2"), "SQ_INSTS_VALU")
+    for k, v in vals.items():
         if k in STAGE_OF and v:
-            valu[STAGE_OF[k]] += sum(v) / len(v)
+            valu[STAGE_OF[k]] += sum(v) / min(passes(vals) or 1 << 30, len(v))
     m = re.fullmatch(r"(\w+?)x(\d+)", key)
     if m:  # bytes per image and stage: what bench.py scales by its own batch
         data.setdefault("per_image", {})[m.group(1)] = {s: v / int(m.group(2)) for s, v in stage.items()}

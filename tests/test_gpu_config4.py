@@ -129,3 +129,30 @@ def test_canny_hysteresis_over_many_regions_of_a_huge_image(h, w):
         finally:
             cv2.set_option("hyst_rounds", 6)
         assert np.array_equal(rb.edges[0], want) and np.array_equal(rb.edges[1], want_flipped), rounds
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("h,w,seed", [(4500, 4300, 1), (1111, 16001, 2), (4130, 4100, 3)])
+def test_canny_on_noisy_images_of_more_than_4096_tiles(h, w, seed):
+    # odd sizes: partial tiles and partial regions at the right and lower border; smoothed noise gives weak chains
+    # that wander through many tiles and regions (the regions keep their state in LDS, launches follow the chains
+    # across region borders, the finishing kernel takes what is left)
+    import imageprocessing_amd as cv2
+
+    assert (-(-w // 128)) * (-(-h // 32)) > 4096
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2), dtype=np.uint8)
+    g = np.kron(g, np.ones((4, 4), np.uint8))[:h, :w]
+    g = (g.astype(np.uint16) // 4 + rng.integers(0, 40, (h, w), dtype=np.uint16) + 60).astype(np.uint8)
+    g = np.ascontiguousarray(g)
+    for lo, hi in ((30, 200), (60, 120)):
+        want = fr.canny(g, lo, hi)
+        assert 0 < int((want > 0).sum()) < h * w
+        assert np.array_equal(cv2.Canny(g, lo, hi), want), (lo, hi)
+    for rounds in (1, 2):
+        cv2.set_option("hyst_rounds", rounds)
+        try:
+            got = cv2.Canny(g, 30, 200)
+        finally:
+            cv2.set_option("hyst_rounds", 6)
+        assert np.array_equal(got, fr.canny(g, 30, 200)), rounds
