@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, re, sys
 STAGE_OF = {
     "k_bgr2gray": "gray_thresh_pack", "k_bgr2gray_flat": "gray_thresh_pack", "k_bitmorph_v": "open_vertical", "k_bitmorph_h3": "open_horizontal",
     "k_bitmorph": "open_horizontal", "k_canny_stream": "canny_nms", "k_canny_nms": "canny_nms",
-    "k_hyst_tiles": "canny_hysteresis", "k_hyst_final": "canny_hysteresis", "k_hough_compact": "hough_compact",
+    "k_hyst_tiles": "canny_hysteresis", "k_hyst_tiles_lds": "canny_hysteresis", "k_hyst_drain": "canny_hysteresis", "k_hyst_final": "canny_hysteresis", "k_hough_compact": "hough_compact",
     "k_hough_vote": "hough_vote", "k_hough_vote_s": "hough_vote", "k_hough_peaks": "hough_peaks",
     "k_hough_peaks_seg": "hough_peaks", "k_hough_compact2": "hough_compact", "k_gauss5_stream": "gaussian_blur",
     "k_canny_wide": "gray_thresh_canny",
