@@ -1337,8 +1337,9 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
     if (fast && kx == 1 && ky > 1 && ky < 256) {
         const int words = cdiv(w, 32);
         int strip_rows = 128;
-        // keep at least ~64k lanes in flight for single images
-        while (strip_rows > 16 && (long long)words * cdiv(h, strip_rows) * batch < 65536) strip_rows /= 2;
+        // keep at least ~128k lanes (2048 waves) in flight for single images (one 16384 x 16384 plane, 201 rows of
+        // kernel: 0.207 ms with strips of 128 rows, 0.177 ms with 64 although a strip then reads 400 rows of run-in)
+        while (strip_rows > 16 && (long long)words * cdiv(h, strip_rows) * batch <= 65536) strip_rows /= 2;
         const int strips = cdiv(h, strip_rows);
         for (int b0 = 0; b0 < batch; b0 += 65535) {
             const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
@@ -1373,9 +1374,13 @@ int launch_bitmorph(const u32* bits, size_t bpw, size_t bsw, Plane dst, int w, i
     const int budget = 8192;  // words per LDS copy (32 KiB); two copies
     int tww, tr;
     if (ky == 1) {
-        // horizontal work: wide tiles, a few rows
+        // horizontal work: wide tiles, a few rows.  Small tiles (12 KiB per copy, five or six workgroups per CU): a
+        // workgroup spends most of its time writing its rows back as bytes, and more of them in flight keep the
+        // stores going (open 201 x 1 of one 16384 x 16384 bit plane: 0.32 ms with 32 KiB per copy, 0.175 ms with 12,
+        // 0.19 ms with 4)
+        const int budget_h = 3072;
         tww = row_words < 256 ? row_words : 256;
-        tr = budget / (tww + A.hlw + A.hrw);
+        tr = budget_h / (tww + A.hlw + A.hrw);
         if (tr > 64) tr = 64;
     } else {
         tww = row_words < 32 ? row_words : 32;
