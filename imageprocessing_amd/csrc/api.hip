@@ -368,9 +368,9 @@ int chunk_init(Chunk& C, const uint8_t* bgr, size_t bgr_pitch, size_t bgr_stride
     double lo = canny_lo, hi = canny_hi;
     if (lo > hi) { double t = lo; lo = hi; hi = t; }
     C.lo = (int)floor(lo), C.hi = (int)floor(hi);
-    // short passes (a few images): the few kilobytes of flags and counters are zeroed inside the gray kernel
+    // short passes (a few images, or one huge one): the flags and counters (up to a megabyte) are zeroed inside the gray kernel
     static const int preclear = getenv("IPA_PRECLEAR") ? atoi(getenv("IPA_PRECLEAR")) : 1;  // 0: separate memsets (A/B)
-    C.precleared = preclear && edges != nullptr && !fused_points() && canny_ws_bytes(width, height, batch) <= 64 * 1024 && batch <= 1024;
+    C.precleared = preclear && edges != nullptr && !fused_points() && canny_ws_bytes(width, height, batch) <= 1024 * 1024 && batch <= 1024;
     // one kernel from BGR to the Canny codes when nothing sits between the gray plane and Canny
     C.wide_np = 0;
     if (edges != nullptr && !blur5x5 && !fused_points()) {
